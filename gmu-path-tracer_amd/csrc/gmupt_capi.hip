@@ -1,0 +1,625 @@
+// C-ABI of libgmupt.so (see include/gmupt.h for the contract and the reference call sites each entry replaces).
+// Host code only; the kernels live in pt_kernels.hip.
+#include "pt_device.hpp"
+#include "../host/sbvh_builder.hpp"
+#include "../host/Camera.hpp"
+
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+static_assert(sizeof(gmupt_bvh_node) == 48, "BVHNode is 48 bytes (Include/BVHWrapper.hpp:13-21)");
+static_assert(sizeof(gmupt_triangle) == 16, "Triangle is 16 bytes (Include/BVHWrapper.hpp:23-27)");
+static_assert(sizeof(gmupt_tri_props) == 32, "TriangleProperties is 32 bytes (Include/BVHWrapper.hpp:29-34)");
+static_assert(sizeof(gmupt_light) == 32, "Light is 32 bytes (Include/Scene.hpp:13-19)");
+static_assert(sizeof(gmupt_material) == 48, "MaterialProperty is 48 bytes (Include/Scene.hpp:43-68)");
+static_assert(sizeof(gmupt_camera_buffer) == 112, "CameraBuffer is 112 bytes (Include/Camera.hpp:8-22)");
+static_assert(offsetof(gmupt_camera_buffer, pixelSize) == 64 && offsetof(gmupt_camera_buffer, randomSeed) == 72 &&
+              offsetof(gmupt_camera_buffer, envColor) == 80 && offsetof(gmupt_camera_buffer, iterationCounter) == 96 &&
+              offsetof(gmupt_camera_buffer, lightCount) == 100 && offsetof(gmupt_camera_buffer, sampleLights) == 104, "Cam cbuffer offsets (structs.h:163-180)");
+static_assert(offsetof(gmupt_bvh_node, max) == 16 && offsetof(gmupt_bvh_node, left) == 32 && offsetof(gmupt_bvh_node, isLeaf) == 40, "BVHNode offsets");
+static_assert(offsetof(gmupt_material, metallic) == 16 && offsetof(gmupt_material, textureIndices) == 32 && offsetof(gmupt_material, materialType) == 44, "MaterialProperty offsets");
+
+namespace gmupt {
+void launch_clear(const RenderParams& p, hipStream_t s);
+void launch_logic(const RenderParams& p, hipStream_t s);
+void launch_scan(const RenderParams& p, int clearFrame, hipStream_t s);
+void launch_material(const RenderParams& p, int clearFrame, hipStream_t s);
+void launch_extend(const RenderParams& p, uint32_t blocks, bool stats, hipStream_t s);
+void launch_shadow(const RenderParams& p, uint32_t blocks, bool stats, hipStream_t s);
+void launch_detmath(int fn, const float* x, const float* y, float* out, uint32_t n, hipStream_t s);
+uint32_t traversal_block_threads();
+uint32_t traversal_overflow_entries();
+}
+using namespace gmupt;
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_lastError;
+
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    g_lastError = buf;
+    return code;
+}
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(GMUPT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+extern "C" const char* gmupt_last_error(void) { return g_lastError.c_str(); }
+extern "C" const char* gmupt_version(void) { return "gmupt 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------------------------------------ device
+struct gmupt_device { int id; hipDeviceProp_t prop; };
+
+extern "C" int gmupt_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(GMUPT_ERR_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    return n;
+}
+
+extern "C" int gmupt_device_create(int hip_device, gmupt_device** out)
+{
+    if (!out) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_device_create: out is null");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (hip_device < 0 || hip_device >= n) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_device_create: device %d of %d", hip_device, n);
+    gmupt_device* d = new (std::nothrow) gmupt_device();
+    if (!d) return fail(GMUPT_ERR_OUT_OF_MEMORY, "gmupt_device_create: out of host memory");
+    d->id = hip_device;
+    hipError_t e = hipSetDevice(hip_device);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&d->prop, hip_device);
+    if (e != hipSuccess) { delete d; return fail(GMUPT_ERR_HIP, "device %d: %s", hip_device, hipGetErrorString(e)); }
+    *out = d;
+    return GMUPT_OK;
+}
+
+extern "C" void gmupt_device_destroy(gmupt_device* dev) { delete dev; }
+
+// ------------------------------------------------------------------------------------------------ buffers
+struct gmupt_buffer { gmupt_device* dev; gmupt_buffer_kind kind; void* dptr; size_t bytes; size_t elems; };
+
+static size_t kind_stride(gmupt_buffer_kind k)
+{
+    switch (k) {
+    case GMUPT_BUFFER_BVH_NODES: return 48; case GMUPT_BUFFER_TRIANGLES: return 16; case GMUPT_BUFFER_VERTICES: return 12;
+    case GMUPT_BUFFER_LIGHTS: return 32; case GMUPT_BUFFER_TRI_PROPS: return 32; case GMUPT_BUFFER_MATERIALS: return 48;
+    }
+    return 0;
+}
+
+extern "C" int gmupt_buffer_create(gmupt_device* dev, gmupt_buffer_kind kind, const void* data, size_t bytes, gmupt_buffer** out)
+{
+    if (!dev || !out) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_buffer_create: null argument");
+    *out = nullptr;
+    const size_t stride = kind_stride(kind);
+    if (!stride) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_buffer_create: unknown kind %d", (int)kind);
+    if (bytes % stride) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_buffer_create: %zu bytes is not a multiple of the %zu-byte element", bytes, stride);
+    if (bytes && !data) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_buffer_create: data is null");
+    size_t alloc = bytes;
+    // lights / materials live in fixed 128-entry tables (Scene.hpp:116, logic.hlsl:8); entries past the data are zero
+    if (kind == GMUPT_BUFFER_LIGHTS || kind == GMUPT_BUFFER_MATERIALS) {
+        if (bytes > stride * GMUPT_MAX_LIGHTS) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_buffer_create: more than %d entries", GMUPT_MAX_LIGHTS);
+        alloc = stride * GMUPT_MAX_LIGHTS;
+    }
+    if (alloc == 0) alloc = stride;
+    gmupt_buffer* b = new (std::nothrow) gmupt_buffer();
+    if (!b) return fail(GMUPT_ERR_OUT_OF_MEMORY, "gmupt_buffer_create: out of host memory");
+    b->dev = dev; b->kind = kind; b->bytes = alloc; b->elems = bytes / stride; b->dptr = nullptr;
+    hipError_t e = hipSetDevice(dev->id);
+    if (e == hipSuccess) e = hipMalloc(&b->dptr, alloc + 16); // +16: 12-byte vertices are read with in-bounds dword loads only, slack is for safety
+    if (e == hipSuccess) e = hipMemset(b->dptr, 0, alloc + 16);
+    if (e == hipSuccess && bytes) e = hipMemcpy(b->dptr, data, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { if (b->dptr) (void)hipFree(b->dptr); delete b; return fail(GMUPT_ERR_HIP, "gmupt_buffer_create(%zu bytes): %s", alloc, hipGetErrorString(e)); }
+    *out = b;
+    return GMUPT_OK;
+}
+
+extern "C" int gmupt_buffer_update(gmupt_buffer* buf, const void* data, size_t bytes)
+{
+    if (!buf || (!data && bytes)) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_buffer_update: null argument");
+    if (bytes > buf->bytes) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_buffer_update: %zu bytes into a %zu-byte buffer", bytes, buf->bytes);
+    HIP_TRY(hipSetDevice(buf->dev->id));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(buf->dptr, data, bytes, hipMemcpyHostToDevice));
+    return GMUPT_OK;
+}
+
+extern "C" void gmupt_buffer_destroy(gmupt_buffer* buf)
+{
+    if (!buf) return;
+    (void)hipSetDevice(buf->dev->id);
+    (void)hipFree(buf->dptr);
+    delete buf;
+}
+
+extern "C" size_t gmupt_buffer_size(const gmupt_buffer* buf) { return buf ? buf->bytes : 0; }
+
+// ------------------------------------------------------------------------------------------------ renderer
+struct StageEvents { hipEvent_t e[6]; };
+
+struct gmupt_renderer {
+    gmupt_device* dev = nullptr;
+    gmupt_renderer_desc desc{};
+    hipStream_t stream = nullptr;
+    RenderParams p{};
+    bool sceneBound = false, cameraSet = false;
+    uint64_t iterations = 0;
+    uint32_t travBlocks = 0;
+    // timing
+    bool timing = false;
+    std::vector<StageEvents> evPool; size_t evUsed = 0;
+    double msStage[5] = { 0, 0, 0, 0, 0 }; uint64_t timedIters = 0;
+    std::vector<void*> allocs;
+};
+
+static int dev_alloc(gmupt_renderer* r, void** ptr, size_t bytes, int fill)
+{
+    *ptr = nullptr;
+    HIP_TRY(hipMalloc(ptr, bytes ? bytes : 16));
+    r->allocs.push_back(*ptr);
+    HIP_TRY(hipMemsetAsync(*ptr, fill, bytes ? bytes : 16, r->stream));
+    return GMUPT_OK;
+}
+
+static int alloc_framebuffer(gmupt_renderer* r, uint32_t w, uint32_t h)
+{
+    void* fb = nullptr; void* head = nullptr;
+    const size_t npix = (size_t)w * h;
+    HIP_TRY(hipMalloc(&fb, npix * 16 + 16));
+    HIP_TRY(hipMalloc(&head, npix * 4 + 16));
+    HIP_TRY(hipMemsetAsync(fb, 0, npix * 16 + 16, r->stream));        // createRenderTexture: no initial data => zero
+    HIP_TRY(hipMemsetAsync(head, 0xFF, npix * 4 + 16, r->stream));
+    r->p.fb = (float4*)fb; r->p.listHead = (uint32_t*)head; r->p.fbW = w; r->p.fbH = h;
+    return GMUPT_OK;
+}
+
+extern "C" void gmupt_renderer_destroy(gmupt_renderer* r)
+{
+    if (!r) return;
+    (void)hipSetDevice(r->dev->id);
+    if (r->stream) (void)hipStreamSynchronize(r->stream);
+    for (auto& se : r->evPool) for (auto& e : se.e) (void)hipEventDestroy(e);
+    for (void* a : r->allocs) (void)hipFree(a);
+    if (r->p.fb) (void)hipFree(r->p.fb);
+    if (r->p.listHead) (void)hipFree(r->p.listHead);
+    if (r->stream) (void)hipStreamDestroy(r->stream);
+    delete r;
+}
+
+extern "C" int gmupt_renderer_create(gmupt_device* dev, const gmupt_renderer_desc* desc, gmupt_renderer** out)
+{
+    if (!dev || !desc || !out) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_renderer_create: null argument");
+    *out = nullptr;
+    if (desc->width == 0 || desc->height == 0) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_renderer_create: empty accumulation target %ux%u", desc->width, desc->height);
+    gmupt_renderer* r = new (std::nothrow) gmupt_renderer();
+    if (!r) return fail(GMUPT_ERR_OUT_OF_MEMORY, "gmupt_renderer_create: out of host memory");
+    r->dev = dev; r->desc = *desc;
+    if (r->desc.pool_paths == 0) r->desc.pool_paths = GMUPT_PATHCOUNT;
+    if (r->desc.live_paths == 0 || r->desc.live_paths > r->desc.pool_paths) r->desc.live_paths = r->desc.pool_paths;
+    const uint32_t P = r->desc.pool_paths, L = r->desc.live_paths;
+    if ((uint64_t)P * F_COUNT * 4ull > (200ull << 30)) { delete r; return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_renderer_create: pool of %u paths is too large", P); }
+
+    hipError_t e = hipSetDevice(dev->id);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete r; return fail(GMUPT_ERR_HIP, "gmupt_renderer_create: %s", hipGetErrorString(e)); }
+
+    RenderParams& p = r->p;
+    p.P = P; p.L = L;
+    p.nBlocks = (L + kBlock - 1) / kBlock;
+    p.tileEnabled = desc->tile_enabled; p.tileX0 = desc->tile_x0; p.tileY0 = desc->tile_y0;
+    p.budget = desc->path_budget; p.maxDepth = desc->max_depth;
+    const uint32_t tb = traversal_block_threads();
+    r->travBlocks = (L + tb - 1) / tb;
+    p.ovfStride = r->travBlocks * tb;
+
+    int rc = GMUPT_OK;
+    // Renderer::createBuffers creates the UAV buffers without initial data: D3D11 zero-initialises them
+    if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.state, (size_t)F_COUNT * P * 4, 0);
+    if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.cls, (size_t)P, CLS_ENDED);
+    if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.listNext, (size_t)P * 4, 0xFF);
+    if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.sample, (size_t)P * 12, 0);
+    if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.blockCounts, (size_t)p.nBlocks * 12, 0);
+    if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.blockOffsets, (size_t)p.nBlocks * 12, 0);
+    if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.queues, (size_t)P * 20, 0);
+    if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.qc, 32, 0);
+    if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.stats, sizeof(DevStats), 0);
+    if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.ovfStack, (size_t)p.ovfStride * traversal_overflow_entries() * 4, 0);
+    if (rc == GMUPT_OK) rc = alloc_framebuffer(r, desc->width, desc->height);
+    if (rc == GMUPT_OK) {
+        DevStats init{}; init.activePaths = L;
+        e = hipMemcpyAsync(p.stats, &init, sizeof(init), hipMemcpyHostToDevice, r->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+        if (e != hipSuccess) rc = fail(GMUPT_ERR_HIP, "gmupt_renderer_create: %s", hipGetErrorString(e));
+    }
+    if (rc != GMUPT_OK) { std::string keep = g_lastError; gmupt_renderer_destroy(r); g_lastError = keep; return rc; }
+    *out = r;
+    return GMUPT_OK;
+}
+
+extern "C" int gmupt_renderer_bind_scene(gmupt_renderer* r, const gmupt_buffer* nodes, const gmupt_buffer* triangles, const gmupt_buffer* vertices,
+                                         const gmupt_buffer* lights, const gmupt_buffer* tri_props, const gmupt_buffer* materials)
+{
+    if (!r || !nodes || !triangles || !vertices || !lights || !tri_props || !materials) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_renderer_bind_scene: null argument");
+    if (nodes->kind != GMUPT_BUFFER_BVH_NODES || triangles->kind != GMUPT_BUFFER_TRIANGLES || vertices->kind != GMUPT_BUFFER_VERTICES ||
+        lights->kind != GMUPT_BUFFER_LIGHTS || tri_props->kind != GMUPT_BUFFER_TRI_PROPS || materials->kind != GMUPT_BUFFER_MATERIALS)
+        return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_renderer_bind_scene: buffer bound to the wrong slot");
+    if (nodes->elems == 0) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_renderer_bind_scene: empty BVH");
+    if (tri_props->elems < vertices->elems) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_renderer_bind_scene: %zu vertex properties for %zu vertices", tri_props->elems, vertices->elems);
+    SceneView& s = r->p.scene;
+    s.nodes = (const DNode*)nodes->dptr; s.tris = (const gmupt_triangle*)triangles->dptr; s.verts = (const float*)vertices->dptr;
+    s.lights = (const gmupt_light*)lights->dptr; s.props = (const gmupt_tri_props*)tri_props->dptr; s.materials = (const gmupt_material*)materials->dptr;
+    s.numNodes = (uint32_t)nodes->elems; s.numTris = (uint32_t)triangles->elems; s.numVerts = (uint32_t)vertices->elems; s.numMaterials = (uint32_t)materials->elems;
+    r->sceneBound = true;
+    return GMUPT_OK;
+}
+
+extern "C" int gmupt_set_camera(gmupt_renderer* r, const gmupt_camera_buffer* cam)
+{
+    if (!r || !cam) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_set_camera: null argument");
+    r->p.cam = *cam; // travels to the kernels as a launch argument: the per-frame 112-byte upload of Renderer.cpp:161
+    r->cameraSet = true;
+    return GMUPT_OK;
+}
+
+static int resolve_timing(gmupt_renderer* r)
+{
+    if (r->evUsed == 0) return GMUPT_OK;
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    for (size_t k = 0; k < r->evUsed; k++) {
+        for (int sidx = 0; sidx < 5; sidx++) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, r->evPool[k].e[sidx], r->evPool[k].e[sidx + 1]));
+            r->msStage[sidx] += ms;
+        }
+        r->timedIters++;
+    }
+    r->evUsed = 0;
+    return GMUPT_OK;
+}
+
+static int run_iteration(gmupt_renderer* r, bool doShade, bool doExtend, bool doShadow)
+{
+    if (!r->sceneBound) return fail(GMUPT_ERR_NOT_BOUND, "gmupt_iterate: no scene bound");
+    if (!r->cameraSet) return fail(GMUPT_ERR_NOT_BOUND, "gmupt_iterate: no camera set");
+    HIP_TRY(hipSetDevice(r->dev->id));
+    const RenderParams& p = r->p;
+    const int clearFrame = (p.cam.iterationCounter == 0) ? 1 : 0; // logic.hlsl:206
+    const bool stats = r->desc.collect_stats != 0;
+    StageEvents* ev = nullptr;
+    if (r->timing && doShade && doExtend && doShadow) {
+        if (r->evUsed == r->evPool.size()) {
+            if (r->evPool.size() >= 4096) { int rc = resolve_timing(r); if (rc != GMUPT_OK) return rc; }
+            else { StageEvents se; for (auto& e : se.e) HIP_TRY(hipEventCreate(&e)); r->evPool.push_back(se); }
+        }
+        ev = &r->evPool[r->evUsed++];
+        HIP_TRY(hipEventRecord(ev->e[0], r->stream));
+    }
+    if (doShade) {
+        if (clearFrame) launch_clear(p, r->stream); else launch_logic(p, r->stream);
+        if (ev) HIP_TRY(hipEventRecord(ev->e[1], r->stream));
+        launch_scan(p, clearFrame, r->stream);
+        if (ev) HIP_TRY(hipEventRecord(ev->e[2], r->stream));
+        launch_material(p, clearFrame, r->stream);
+        if (ev) HIP_TRY(hipEventRecord(ev->e[3], r->stream));
+    }
+    if (doExtend) { launch_extend(p, r->travBlocks, stats, r->stream); if (ev) HIP_TRY(hipEventRecord(ev->e[4], r->stream)); }
+    if (doShadow) { launch_shadow(p, r->travBlocks, stats, r->stream); if (ev) HIP_TRY(hipEventRecord(ev->e[5], r->stream)); }
+    HIP_TRY(hipGetLastError());
+    return GMUPT_OK;
+}
+
+extern "C" int gmupt_iterate(gmupt_renderer* r)
+{
+    if (!r) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_iterate: null renderer");
+    int rc = run_iteration(r, true, true, true);
+    if (rc == GMUPT_OK) r->iterations++;
+    return rc;
+}
+
+extern "C" int gmupt_debug_run_stage(gmupt_renderer* r, gmupt_stage stage)
+{
+    if (!r) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_debug_run_stage: null renderer");
+    switch (stage) {
+    case GMUPT_STAGE_SHADE: return run_iteration(r, true, false, false);
+    case GMUPT_STAGE_EXTEND: return run_iteration(r, false, true, false);
+    case GMUPT_STAGE_SHADOW: return run_iteration(r, false, false, true);
+    }
+    return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_debug_run_stage: unknown stage %d", (int)stage);
+}
+
+extern "C" int gmupt_synchronize(gmupt_renderer* r)
+{
+    if (!r) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_synchronize: null renderer");
+    HIP_TRY(hipSetDevice(r->dev->id));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return GMUPT_OK;
+}
+
+extern "C" int gmupt_resize(gmupt_renderer* r, uint32_t width, uint32_t height)
+{
+    if (!r || width == 0 || height == 0) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_resize: bad argument");
+    HIP_TRY(hipSetDevice(r->dev->id));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    HIP_TRY(hipFree(r->p.fb)); r->p.fb = nullptr;
+    HIP_TRY(hipFree(r->p.listHead)); r->p.listHead = nullptr;
+    r->desc.width = width; r->desc.height = height;
+    return alloc_framebuffer(r, width, height);
+}
+
+extern "C" int gmupt_read_framebuffer(gmupt_renderer* r, float* rgba, size_t bytes)
+{
+    if (!r || !rgba) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_read_framebuffer: null argument");
+    const size_t need = (size_t)r->p.fbW * r->p.fbH * 16;
+    if (bytes < need) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_read_framebuffer: %zu bytes given, %zu needed", bytes, need);
+    HIP_TRY(hipSetDevice(r->dev->id));
+    HIP_TRY(hipMemcpyAsync(rgba, r->p.fb, need, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return GMUPT_OK;
+}
+
+extern "C" int gmupt_copy_framebuffer_to_device(gmupt_renderer* r, void* device_dst, size_t bytes)
+{
+    if (!r || !device_dst) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_copy_framebuffer_to_device: null argument");
+    const size_t need = (size_t)r->p.fbW * r->p.fbH * 16;
+    if (bytes < need) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_copy_framebuffer_to_device: %zu bytes given, %zu needed", bytes, need);
+    HIP_TRY(hipSetDevice(r->dev->id));
+    HIP_TRY(hipMemcpyAsync(device_dst, r->p.fb, need, hipMemcpyDeviceToDevice, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return GMUPT_OK;
+}
+
+extern "C" int gmupt_get_counters(gmupt_renderer* r, uint32_t out[8])
+{
+    if (!r || !out) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_get_counters: null argument");
+    HIP_TRY(hipSetDevice(r->dev->id));
+    HIP_TRY(hipMemcpyAsync(out, r->p.qc, 32, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return GMUPT_OK;
+}
+
+extern "C" int gmupt_enable_timing(gmupt_renderer* r, int enabled)
+{
+    if (!r) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_enable_timing: null renderer");
+    if (!enabled) { int rc = resolve_timing(r); if (rc != GMUPT_OK) return rc; }
+    r->timing = enabled != 0;
+    return GMUPT_OK;
+}
+
+extern "C" int gmupt_get_stats(gmupt_renderer* r, gmupt_stats* out)
+{
+    if (!r || !out) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_get_stats: null argument");
+    HIP_TRY(hipSetDevice(r->dev->id));
+    int rc = resolve_timing(r);
+    if (rc != GMUPT_OK) return rc;
+    DevStats ds;
+    HIP_TRY(hipMemcpyAsync(&ds, r->p.stats, sizeof(ds), hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    std::memset(out, 0, sizeof(*out));
+    out->iterations = r->iterations;
+    out->paths_generated = ds.pathsGenerated; out->paths_completed = ds.pathsCompleted; out->segments = ds.segments;
+    out->active_paths = ds.activePaths; out->reserved_ = ds.stackOverflow;
+    out->ext_rays = ds.extRays; out->ext_inner = ds.extInner; out->ext_leaves = ds.extLeaves; out->ext_tris = ds.extTris;
+    out->sh_rays = ds.shRays; out->sh_inner = ds.shInner; out->sh_leaves = ds.shLeaves; out->sh_tris = ds.shTris;
+    out->ms_logic = r->msStage[0]; out->ms_scan = r->msStage[1]; out->ms_material = r->msStage[2];
+    out->ms_accumulate = 0.0; // accumulation is fused into the material kernel
+    out->ms_extend = r->msStage[3]; out->ms_shadow = r->msStage[4];
+    out->timed_iterations = r->timedIters;
+    return GMUPT_OK;
+}
+
+extern "C" int gmupt_reset_stats(gmupt_renderer* r)
+{
+    if (!r) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_reset_stats: null renderer");
+    HIP_TRY(hipSetDevice(r->dev->id));
+    int rc = resolve_timing(r);
+    if (rc != GMUPT_OK) return rc;
+    DevStats ds;
+    HIP_TRY(hipMemcpyAsync(&ds, r->p.stats, sizeof(ds), hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    const uint32_t active = ds.activePaths;
+    std::memset(&ds, 0, sizeof(ds)); ds.activePaths = active;
+    HIP_TRY(hipMemcpyAsync(r->p.stats, &ds, sizeof(ds), hipMemcpyHostToDevice, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    for (double& m : r->msStage) m = 0.0;
+    r->timedIters = 0; r->iterations = 0;
+    return GMUPT_OK;
+}
+
+struct gmupt_camera { Camera cam; gmupt_camera(uint32_t w, uint32_t h) : cam(w, h) {} };
+
+extern "C" int gmupt_render_budget(gmupt_renderer* r, gmupt_camera* cam, uint32_t max_iterations, uint32_t* iters)
+{
+    if (!r || !cam) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_render_budget: null argument");
+    if (!r->desc.path_budget) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_render_budget: renderer was created without a path_budget");
+    HIP_TRY(hipSetDevice(r->dev->id));
+    uint32_t* hostActive = nullptr;
+    HIP_TRY(hipHostMalloc((void**)&hostActive, 4, hipHostMallocDefault));
+    *hostActive = 1;
+    uint32_t k = 0;
+    int rc = GMUPT_OK;
+    for (; k < max_iterations; k++) {
+        cam->cam.update(0.0f);                       // Renderer::update -> Scene::update -> Camera::update (Renderer.cpp:158)
+        rc = gmupt_set_camera(r, cam->cam.getBuffer());
+        if (rc == GMUPT_OK) rc = gmupt_iterate(r);   // Renderer::draw
+        if (rc != GMUPT_OK) break;
+        if ((k & 7u) == 7u) {                        // drain check without stalling every iteration
+            hipError_t e = hipMemcpyAsync(hostActive, &r->p.stats->activePaths, 4, hipMemcpyDeviceToHost, r->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+            if (e != hipSuccess) { rc = fail(GMUPT_ERR_HIP, "gmupt_render_budget: %s", hipGetErrorString(e)); break; }
+            if (*hostActive == 0) { k++; break; }
+        }
+    }
+    (void)hipHostFree(hostActive);
+    if (rc == GMUPT_OK) { hipError_t e = hipStreamSynchronize(r->stream); if (e != hipSuccess) rc = fail(GMUPT_ERR_HIP, "gmupt_render_budget: %s", hipGetErrorString(e)); }
+    if (iters) *iters = k;
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------ debug access (reference layout)
+namespace {
+struct FieldMap { uint32_t refOffset, slotBytes, comps, first; };
+// Assets/Shaders/structs.h:19-48 (offset in bytes per path, x PATHCOUNT) -> first SoA component
+const FieldMap kFieldMap[] = {
+    { 0, 16, 3, F_RAY_OX }, { 16, 16, 3, F_RAY_DX }, { 32, 16, 3, F_MAT_R }, { 48, 8, 2, F_MAT_METALLIC }, { 56, 16, 3, F_NRM_X },
+    { 72, 16, 3, F_SP_X }, { 88, 16, 3, F_BARY_X }, { 104, 4, 1, F_HIT_DIST }, { 108, 16, 4, F_TRI_0 }, { 124, 16, 3, F_SH_OX },
+    { 140, 16, 3, F_SH_DX }, { 156, 4, 1, F_LIGHT_IDX }, { 160, 4, 1, F_LIGHT_DIST }, { 164, 4, 1, F_IN_SHADOW }, { 168, 16, 3, F_RAD_R },
+    { 184, 16, 3, F_THR_R }, { 200, 16, 3, F_LTHR_R }, { 216, 16, 3, F_DL_R }, { 232, 4, 1, F_PATH_LEN }, { 236, 8, 2, F_SCR_X }, { 244, 4, 1, F_IS_EMITTER },
+};
+}
+
+extern "C" int gmupt_debug_read_path_state(gmupt_renderer* r, void* dst, size_t bytes)
+{
+    if (!r || !dst) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_debug_read_path_state: null argument");
+    const size_t P = r->p.P;
+    if (bytes < P * GMUPT_STATE_BYTES) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_debug_read_path_state: %zu bytes given, %zu needed", bytes, P * (size_t)GMUPT_STATE_BYTES);
+    HIP_TRY(hipSetDevice(r->dev->id));
+    std::vector<uint32_t> soa((size_t)F_COUNT * P);
+    HIP_TRY(hipMemcpyAsync(soa.data(), r->p.state, soa.size() * 4, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    std::memset(dst, 0, P * GMUPT_STATE_BYTES);
+    uint8_t* out = (uint8_t*)dst;
+    for (const FieldMap& f : kFieldMap)
+        for (size_t i = 0; i < P; i++) {
+            uint32_t* o = (uint32_t*)(out + (size_t)f.refOffset * P + (size_t)f.slotBytes * i);
+            for (uint32_t c = 0; c < f.comps; c++) o[c] = soa[(size_t)(f.first + c) * P + i];
+        }
+    return GMUPT_OK;
+}
+
+extern "C" int gmupt_debug_write_path_state(gmupt_renderer* r, const void* src, size_t bytes)
+{
+    if (!r || !src) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_debug_write_path_state: null argument");
+    const size_t P = r->p.P;
+    if (bytes < P * GMUPT_STATE_BYTES) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_debug_write_path_state: %zu bytes given, %zu needed", bytes, P * (size_t)GMUPT_STATE_BYTES);
+    HIP_TRY(hipSetDevice(r->dev->id));
+    std::vector<uint32_t> soa((size_t)F_COUNT * P);
+    const uint8_t* in = (const uint8_t*)src;
+    for (const FieldMap& f : kFieldMap)
+        for (size_t i = 0; i < P; i++) {
+            const uint32_t* o = (const uint32_t*)(in + (size_t)f.refOffset * P + (size_t)f.slotBytes * i);
+            for (uint32_t c = 0; c < f.comps; c++) soa[(size_t)(f.first + c) * P + i] = o[c];
+        }
+    HIP_TRY(hipMemcpyAsync(r->p.state, soa.data(), soa.size() * 4, hipMemcpyHostToDevice, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return GMUPT_OK;
+}
+
+extern "C" int gmupt_debug_read_queues(gmupt_renderer* r, uint32_t* dst, size_t bytes)
+{
+    if (!r || !dst) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_debug_read_queues: null argument");
+    const size_t need = (size_t)r->p.P * 20;
+    if (bytes < need) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_debug_read_queues: %zu bytes given, %zu needed", bytes, need);
+    HIP_TRY(hipSetDevice(r->dev->id));
+    HIP_TRY(hipMemcpyAsync(dst, r->p.queues, need, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return GMUPT_OK;
+}
+
+extern "C" int gmupt_debug_write_queues(gmupt_renderer* r, const uint32_t* src, size_t bytes)
+{
+    if (!r || !src) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_debug_write_queues: null argument");
+    const size_t need = (size_t)r->p.P * 20;
+    if (bytes < need) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_debug_write_queues: %zu bytes given, %zu needed", bytes, need);
+    HIP_TRY(hipSetDevice(r->dev->id));
+    HIP_TRY(hipMemcpyAsync(r->p.queues, src, need, hipMemcpyHostToDevice, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return GMUPT_OK;
+}
+
+extern "C" int gmupt_debug_write_counters(gmupt_renderer* r, const uint32_t in[8])
+{
+    if (!r || !in) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_debug_write_counters: null argument");
+    HIP_TRY(hipSetDevice(r->dev->id));
+    HIP_TRY(hipMemcpyAsync(r->p.qc, in, 32, hipMemcpyHostToDevice, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return GMUPT_OK;
+}
+
+extern "C" int gmupt_debug_write_framebuffer(gmupt_renderer* r, const float* rgba, size_t bytes)
+{
+    if (!r || !rgba) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_debug_write_framebuffer: null argument");
+    const size_t need = (size_t)r->p.fbW * r->p.fbH * 16;
+    if (bytes < need) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_debug_write_framebuffer: %zu bytes given, %zu needed", bytes, need);
+    HIP_TRY(hipSetDevice(r->dev->id));
+    HIP_TRY(hipMemcpyAsync(r->p.fb, rgba, need, hipMemcpyHostToDevice, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return GMUPT_OK;
+}
+
+extern "C" int gmupt_debug_detmath(gmupt_device* dev, int fn, const float* x, const float* y, float* out, uint32_t n)
+{
+    if (!dev || !x || !y || !out) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_debug_detmath: null argument");
+    if (n == 0) return GMUPT_OK;
+    HIP_TRY(hipSetDevice(dev->id));
+    float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc((void**)&dx, (size_t)n * 4)); HIP_TRY(hipMalloc((void**)&dy, (size_t)n * 4)); HIP_TRY(hipMalloc((void**)&dout, (size_t)n * 4));
+    HIP_TRY(hipMemcpy(dx, x, (size_t)n * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(dy, y, (size_t)n * 4, hipMemcpyHostToDevice));
+    launch_detmath(fn, dx, dy, dout, n, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
+    return GMUPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ host: SBVH
+struct gmupt_sbvh { gmupt::SbvhBuilder* b; };
+
+extern "C" void gmupt_sbvh_default_params(gmupt_sbvh_params* p)
+{
+    if (!p) return;
+    p->split_alpha = 1.0e-5f; p->max_depth = 64; p->max_spatial_depth = 48; p->min_leaf_size = 1; p->max_leaf_size = 0x7FFFFFF;
+    p->node_cost = 1.0f; p->tri_cost = 1.0f;
+}
+
+extern "C" int gmupt_sbvh_build(const float* vertices, uint32_t num_vertices, const int32_t* indices, uint32_t num_triangles,
+                                const gmupt_sbvh_params* params, gmupt_sbvh** out)
+{
+    if (!out || (!vertices && num_vertices) || (!indices && num_triangles)) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_sbvh_build: null argument");
+    *out = nullptr;
+    gmupt_sbvh_params prm; gmupt_sbvh_default_params(&prm);
+    if (params) prm = *params;
+    if (prm.max_depth < 1 || prm.max_depth > 64) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_sbvh_build: max_depth %d outside [1, 64]", prm.max_depth);
+    try {
+        gmupt_sbvh* h = new gmupt_sbvh();
+        h->b = new gmupt::SbvhBuilder(vertices, num_vertices, indices, num_triangles, prm);
+        h->b->build();
+        *out = h;
+    } catch (const std::exception& e) {
+        return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_sbvh_build: %s", e.what());
+    }
+    return GMUPT_OK;
+}
+extern "C" uint32_t gmupt_sbvh_num_nodes(const gmupt_sbvh* h) { return h ? (uint32_t)h->b->nodes().size() : 0; }
+extern "C" uint32_t gmupt_sbvh_num_references(const gmupt_sbvh* h) { return h ? (uint32_t)h->b->refTriangles().size() : 0; }
+extern "C" float gmupt_sbvh_sah(const gmupt_sbvh* h) { return h ? h->b->sah() : 0.0f; }
+extern "C" uint32_t gmupt_sbvh_depth(const gmupt_sbvh* h) { return h ? h->b->depth() : 0; }
+extern "C" int gmupt_sbvh_flatten(const gmupt_sbvh* h, const uint32_t* vertex_material, gmupt_bvh_node* nodes, gmupt_triangle* triangles, int32_t* ref_triangle)
+{
+    if (!h || !nodes) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_sbvh_flatten: null argument");
+    h->b->flatten(vertex_material, nodes, triangles, ref_triangle);
+    return GMUPT_OK;
+}
+extern "C" void gmupt_sbvh_destroy(gmupt_sbvh* h) { if (h) { delete h->b; delete h; } }
+
+// ------------------------------------------------------------------------------------------------ host: camera
+extern "C" int gmupt_camera_create(uint32_t width, uint32_t height, gmupt_camera** out)
+{
+    if (!out || !width || !height) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_camera_create: bad argument");
+    *out = new (std::nothrow) gmupt_camera(width, height);
+    return *out ? GMUPT_OK : fail(GMUPT_ERR_OUT_OF_MEMORY, "gmupt_camera_create: out of host memory");
+}
+extern "C" void gmupt_camera_destroy(gmupt_camera* c) { delete c; }
+extern "C" void gmupt_camera_update_resolution(gmupt_camera* c, uint32_t width, uint32_t height) { if (c) c->cam.updateResolution(width, height); }
+extern "C" void gmupt_camera_set_pose(gmupt_camera* c, float x, float y, float z, float pitch, float yaw) { if (c) { c->cam.setPosition(x, y, z); c->cam.setRotation(pitch, yaw); } }
+extern "C" void gmupt_camera_update(gmupt_camera* c, float dt) { if (c) c->cam.update(dt); }
+extern "C" void gmupt_camera_reset_accumulation(gmupt_camera* c) { if (c) c->cam.getBuffer()->iterationCounter = -1; }
+extern "C" gmupt_camera_buffer* gmupt_camera_get_buffer(gmupt_camera* c) { return c ? c->cam.getBuffer() : nullptr; }

@@ -1,0 +1,89 @@
+// Device-side data layout of the wavefront path tracer (gfx950).
+//
+// Path state: the reference keeps 21 fields in one raw buffer, SoA by field with float3 in 16-byte slots
+// (Assets/Shaders/structs.h:19-48, 248 B/path).  Here every scalar component is its own array of P words
+// (50 words = 200 B/path, no padding): a wave reads one component of 64 consecutive slots as one 256-byte
+// coalesced transaction.  gmupt_debug_{read,write}_path_state convert to/from the reference layout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "../../include/gmupt.h"
+
+namespace gmupt {
+
+enum Field : uint32_t {
+    F_RAY_OX, F_RAY_OY, F_RAY_OZ, F_RAY_DX, F_RAY_DY, F_RAY_DZ,
+    F_MAT_R, F_MAT_G, F_MAT_B, F_MAT_METALLIC, F_MAT_ROUGHNESS,
+    F_NRM_X, F_NRM_Y, F_NRM_Z,
+    F_SP_X, F_SP_Y, F_SP_Z,
+    F_BARY_X, F_BARY_Y, F_BARY_Z,
+    F_HIT_DIST,
+    F_TRI_0, F_TRI_1, F_TRI_2, F_TRI_MAT,
+    F_SH_OX, F_SH_OY, F_SH_OZ, F_SH_DX, F_SH_DY, F_SH_DZ,
+    F_LIGHT_IDX, F_LIGHT_DIST, F_IN_SHADOW,
+    F_RAD_R, F_RAD_G, F_RAD_B,
+    F_THR_R, F_THR_G, F_THR_B,
+    F_LTHR_R, F_LTHR_G, F_LTHR_B,
+    F_DL_R, F_DL_G, F_DL_B,
+    F_PATH_LEN, F_SCR_X, F_SCR_Y, F_IS_EMITTER,
+    F_COUNT
+};
+static_assert(F_COUNT == 50, "50 words per path");
+
+// per-slot class written by the logic kernel, consumed by the material kernel
+enum SlotClass : uint8_t { CLS_UE4 = 0, CLS_GLASS = 1, CLS_ENDED = 2, CLS_RETIRED = 3, CLS_NONE = 4 };
+
+// queue counters, same indices as the reference (structs.h:62-68); [7] is this build's live extension-queue length
+enum Counter : uint32_t { QC_NEWPATH = 0, QC_LASTPATHCNT = 1, QC_MATUE4 = 2, QC_MATGLASS = 3, QC_EXT_UE4_OFFSET = 4, QC_EXT_GLASS_OFFSET = 5, QC_SHADOWRAY = 6, QC_EXT_COUNT = 7 };
+// queues, same order as the reference (structs.h:53-58): queue q lives at queues + q * P
+enum Queue : uint32_t { Q_NEWPATH = 0, Q_MAT_UE4 = 1, Q_MAT_GLASS = 2, Q_EXT_RAY = 3, Q_SHADOW_RAY = 4 };
+
+constexpr uint32_t kQueueHole = 0xFFFFFFFFu; // extension-queue entry of a slot retired by path_budget
+constexpr uint32_t kListEnd = 0xFFFFFFFFu;
+constexpr int kBlock = 256;
+
+struct DevStats {
+    unsigned long long pathsGenerated, pathsCompleted, segments;
+    unsigned long long extRays, extInner, extLeaves, extTris;
+    unsigned long long shRays, shInner, shLeaves, shTris;
+    uint32_t activePaths;
+    uint32_t stackOverflow; // traversal needed more than the provisioned stack (results then differ from an unbounded stack)
+};
+
+struct alignas(16) DNode { float4 mn; float4 mx; int4 link; }; // gmupt_bvh_node, 48 B: link = (left, right, isLeaf, pad)
+static_assert(sizeof(DNode) == sizeof(gmupt_bvh_node), "node layout");
+
+struct SceneView {
+    const DNode* nodes;
+    const gmupt_triangle* tris;
+    const float* verts;
+    const gmupt_light* lights;
+    const gmupt_tri_props* props;
+    const gmupt_material* materials;
+    uint32_t numNodes, numTris, numVerts, numMaterials;
+};
+
+struct RenderParams {
+    float* state;          // F_COUNT * P words
+    uint32_t P, L;         // pool / live slots
+    uint8_t* cls;          // P
+    uint32_t* listNext;    // P: per-pixel list of paths that ended this iteration
+    uint32_t* listHead;    // fbW * fbH
+    float* sample;         // 3 * P: tonemapped sample of an ended path
+    uint32_t* blockCounts; // 3 * nBlocks
+    uint32_t* blockOffsets;// 3 * nBlocks
+    uint32_t nBlocks;
+    uint32_t* queues;      // 5 * P
+    uint32_t* qc;          // 8
+    DevStats* stats;
+    float4* fb;
+    uint32_t fbW, fbH;
+    uint32_t tileEnabled, tileX0, tileY0;
+    uint32_t budget, maxDepth;
+    int* ovfStack;         // global overflow of the traversal stacks
+    uint32_t ovfStride;    // threads of the traversal grid
+    gmupt_camera_buffer cam;
+    SceneView scene;
+};
+
+} // namespace gmupt

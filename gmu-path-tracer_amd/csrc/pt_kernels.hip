@@ -1,0 +1,770 @@
+// Wavefront path-tracing kernels for gfx950 (MI355X).  Hand-written HIP; wave64 throughout.
+//
+// One wavefront iteration = the six dispatches of the reference's Renderer::draw()
+// (Source/Renderer.cpp:195-211), regrouped for CDNA4:
+//
+//   k_logic      logic.hlsl:200-302 per slot: terminate / accumulate decision, material fetch, NEE set-up.
+//                Writes a 1-byte class per slot and per-block class counts instead of pushing to queues
+//                with per-warp atomics (the reference's NvBallot + InterlockedAdd idiom, logic.hlsl:36-44,
+//                263-285): queue positions are then RANKS, independent of scheduling order.
+//   k_scan       exclusive scan of the block counts (one workgroup) -> queue offsets + the seven counters.
+//   k_material   rank of every slot inside its class by wave64 ballot + mbcnt + block offset, then, fused by
+//                class: framebuffer accumulation (logic.hlsl:49-73) + newPath.hlsl:14-61, materialUE4.hlsl:118-192,
+//                materialGlass.hlsl:48-85.  The RNG of those stages is seeded by the queue index
+//                (newPath.hlsl:27, materialUE4.hlsl:131, materialGlass.hlsl:61), so ranks must be the
+//                canonical ones (ascending slot order) -- which a scan gives and atomics do not.
+//   k_extend     extensionRayCast.hlsl:197-234, closest hit + light spheres, per-wave LDS traversal stacks.
+//   k_shadow     shadowRayCast.hlsl:139-169, any hit; thread 0 performs the counter hand-over (:144-148).
+//
+// Arithmetic: every float expression is evaluated in the reference's written order with IEEE binary32
+// operations and no FMA contraction; sin/cos/exp2/log2 come from detmath.hpp.  The CPU oracle (oracle/) states
+// the same sequence independently; tests compare the two bit for bit.
+#include "pt_device.hpp"
+#include "detmath.hpp"
+
+namespace gmupt {
+
+// ------------------------------------------------------------------------------------------------ helpers
+__device__ __forceinline__ float ldf(const RenderParams& p, uint32_t f, uint32_t i) { return p.state[(size_t)f * p.P + i]; }
+__device__ __forceinline__ uint32_t ldu(const RenderParams& p, uint32_t f, uint32_t i) { return __builtin_bit_cast(uint32_t, p.state[(size_t)f * p.P + i]); }
+__device__ __forceinline__ void stf(const RenderParams& p, uint32_t f, uint32_t i, float v) { p.state[(size_t)f * p.P + i] = v; }
+__device__ __forceinline__ void stu(const RenderParams& p, uint32_t f, uint32_t i, uint32_t v) { p.state[(size_t)f * p.P + i] = __builtin_bit_cast(float, v); }
+__device__ __forceinline__ f3 ld3(const RenderParams& p, uint32_t f, uint32_t i) { return mk3(ldf(p, f, i), ldf(p, f + 1, i), ldf(p, f + 2, i)); }
+__device__ __forceinline__ void st3(const RenderParams& p, uint32_t f, uint32_t i, f3 v) { stf(p, f, i, v.x); stf(p, f + 1, i, v.y); stf(p, f + 2, i, v.z); }
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// number of set bits of a 64-bit wave mask below this lane (the reference's NvWaveMultiPrefixExclusiveAdd(1, ballot))
+__device__ __forceinline__ uint32_t prefix_rank(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__device__ __forceinline__ uint32_t cam_width(const gmupt_camera_buffer& c) { return (uint32_t)(1.0f / c.pixelSize[0]); }  // newPath.hlsl:30
+__device__ __forceinline__ uint32_t cam_height(const gmupt_camera_buffer& c) { return (uint32_t)(1.0f / c.pixelSize[1]); } // newPath.hlsl:31
+
+// local pixel index of a global screen coordinate, or kListEnd when outside the accumulation target
+__device__ __forceinline__ uint32_t pixel_index(const RenderParams& p, uint32_t cx, uint32_t cy)
+{
+    uint32_t lx = cx - (p.tileEnabled ? p.tileX0 : 0u), ly = cy - (p.tileEnabled ? p.tileY0 : 0u);
+    if (lx >= p.fbW || ly >= p.fbH) return kListEnd;
+    return ly * p.fbW + lx;
+}
+
+// ------------------------------------------------------------------------------------------------ bsdf.h
+__device__ __forceinline__ float schlickFresnel(float r0, float theta) // bsdf.h:1-6
+{
+    float m = hsaturate(1.0f - theta);
+    float m2 = m * m;
+    return r0 - (1.0f - r0) * m2 * m2 * m;
+}
+__device__ __forceinline__ float GGXTrowbridgeReitz(float XdotY, float alpha) // bsdf.h:8-13
+{
+    float a2 = alpha * alpha;
+    float x = XdotY * XdotY * (a2 - 1.0f) + 1.0f;
+    return a2 / (kPi * x * x);
+}
+__device__ __forceinline__ float smithSchlickGGX(float XdotY, float alpha) // bsdf.h:15-20
+{
+    float a1 = alpha + 1.0f;
+    float k = (a1 * a1) / 8.0f;
+    return XdotY / (XdotY * (1.0f - k) + k);
+}
+__device__ __forceinline__ float lightFalloff(float distance, float radius) // bsdf.h:22-26
+{
+    float q = distance / radius;
+    float q2 = q * q;
+    float n = hsaturate(1.0f - q2 * q2);
+    return (n * n) / (distance * distance + 1.0f);
+}
+__device__ __forceinline__ float powerHeuristic(float rayPdf, float lightPdf) // bsdf.h:28-32
+{
+    float t = rayPdf * rayPdf;
+    return t / (lightPdf * lightPdf + t);
+}
+
+// ------------------------------------------------------------------------------------------------ block class counts
+// every thread of the block calls this once; writes blockCounts[k * nBlocks + blockIdx.x] for k = 0..2
+__device__ __forceinline__ void publish_block_counts(const RenderParams& p, int c)
+{
+    __shared__ uint32_t s_cnt[3][kBlock / 64];
+    const uint32_t wave = threadIdx.x >> 6;
+    unsigned long long b0 = __ballot(c == CLS_UE4), b1 = __ballot(c == CLS_GLASS), b2 = __ballot(c == CLS_ENDED);
+    if ((threadIdx.x & 63) == 0) { s_cnt[0][wave] = __popcll(b0); s_cnt[1][wave] = __popcll(b1); s_cnt[2][wave] = __popcll(b2); }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        uint32_t s = 0;
+        for (int w = 0; w < kBlock / 64; w++) s += s_cnt[threadIdx.x][w];
+        p.blockCounts[threadIdx.x * p.nBlocks + blockIdx.x] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ k_clear (logic.hlsl:165-190)
+__global__ __launch_bounds__(kBlock) void k_clear(RenderParams p)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    // zero the sample count of every pixel, keep the colour (logic.hlsl:180-181)
+    uint32_t w = p.tileEnabled ? p.fbW : cam_width(p.cam), h = p.tileEnabled ? p.fbH : cam_height(p.cam);
+    uint32_t npix = w * h; if (npix > p.fbW * p.fbH) npix = p.fbW * p.fbH;
+    for (uint32_t k = i; k < npix; k += gridDim.x * kBlock) { p.fb[k].w = __builtin_bit_cast(float, 0u); p.listHead[k] = kListEnd; }
+    // newPath[i] = i for the whole pool (logic.hlsl:187-188): every live slot becomes an ended path of rank i
+    int c = CLS_NONE;
+    if (i < p.L) { c = CLS_ENDED; p.cls[i] = CLS_ENDED; }
+    publish_block_counts(p, c);
+}
+
+// ------------------------------------------------------------------------------------------------ k_logic (logic.hlsl:200-302)
+__global__ __launch_bounds__(kBlock) void k_logic(RenderParams p)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    int c = CLS_NONE;
+    if (i < p.L) {
+        c = p.cls[i];
+        if (c != CLS_RETIRED) {
+            Rng g; g.seed(i, p.cam.randomSeed[0], p.cam.randomSeed[1]);     // :216
+            bool pathEliminated = false;                                   // :217
+            f3 throughput = ld3(p, F_THR_R, i);                             // :219
+            f3 radiance = ld3(p, F_RAD_R, i);                               // :220
+            const uint32_t isEmitter = ldu(p, F_IS_EMITTER, i);
+            uint32_t pl = 0;
+            if (isEmitter > 0) {                                            // :222-226, sampleLight :192-197
+                uint32_t li = isEmitter - 1; if (li >= GMUPT_MAX_LIGHTS) li = GMUPT_MAX_LIGHTS - 1;
+                const gmupt_light L = p.scene.lights[li];
+                float emax = hmax(L.emission[0], hmax(L.emission[1], L.emission[2]));
+                f3 e = mk3(L.emission[0] / emax, L.emission[1] / emax, L.emission[2] / emax);
+                radiance = radiance + e * throughput;
+                pathEliminated = true;
+            } else {
+                if (!ldu(p, F_IN_SHADOW, i)) radiance = radiance + ld3(p, F_DL_R, i) * throughput; // :230-231
+                throughput = throughput * ld3(p, F_LTHR_R, i);              // :234
+                if (throughput.x <= 0.0f && throughput.y <= 0.0f && throughput.z <= 0.0f) pathEliminated = true; // :237
+                if (ldf(p, F_HIT_DIST, i) == kFltMax) {                     // :241-245
+                    radiance = radiance + throughput * mk3(p.cam.envColor[0], p.cam.envColor[1], p.cam.envColor[2]);
+                    pathEliminated = true;
+                }
+                pl = ldu(p, F_PATH_LEN, i);
+                if (pl > 200) {                                             // :248-255
+                    float pr = hmax(throughput.x, hmax(throughput.y, throughput.z));
+                    if (g.next() > pr * 0.004f) pathEliminated = true;
+                    throughput = throughput * (1.0f / pr);
+                }
+                if (p.maxDepth && pl >= p.maxDepth) pathEliminated = true;  // extension
+            }
+
+            if (pathEliminated) {
+                // endPath :49-53: per-sample tonemap; the running-mean update is applied in canonical order by k_material
+                c = CLS_ENDED;
+                f3 r = mk3(hsaturate(radiance.x), hsaturate(radiance.y), hsaturate(radiance.z));
+                r = r / (r + mk3(1.0f, 1.0f, 1.0f));
+                const float gm = 1.0f / 2.2f;
+                r = mk3(dpow(r.x, gm), dpow(r.y, gm), dpow(r.z, gm));
+                p.sample[i] = r.x; p.sample[(size_t)p.P + i] = r.y; p.sample[(size_t)2 * p.P + i] = r.z;
+                const uint32_t pix = pixel_index(p, ldu(p, F_SCR_X, i), ldu(p, F_SCR_Y, i));
+                uint32_t prev = kListEnd;
+                if (pix != kListEnd) prev = atomicExch(&p.listHead[pix], i);
+                p.listNext[i] = prev;
+            } else {
+                // setMaterialHitProperties :79-133 (texture-free)
+                const uint32_t t0 = ldu(p, F_TRI_0, i), t1 = ldu(p, F_TRI_1, i), t2 = ldu(p, F_TRI_2, i), tm = ldu(p, F_TRI_MAT, i);
+                const uint32_t i0 = (uint32_t)(float)t0, i1 = (uint32_t)(float)t1, i2 = (uint32_t)(float)t2; // :82 float round trip
+                const f3 bary = ld3(p, F_BARY_X, i);
+                const gmupt_tri_props* tp = p.scene.props;
+                f3 n0 = mk3(tp[i0].normal[0], tp[i0].normal[1], tp[i0].normal[2]);
+                f3 n1 = mk3(tp[i1].normal[0], tp[i1].normal[1], tp[i1].normal[2]);
+                f3 n2 = mk3(tp[i2].normal[0], tp[i2].normal[1], tp[i2].normal[2]);
+                f3 normal = (n0 * bary.x + n1 * bary.y) + n2 * bary.z;      // :94
+                const gmupt_material m = p.scene.materials[tm < GMUPT_MAX_LIGHTS ? tm : 0u]; // :96
+                const float rough = hmax(0.014f, m.roughness);             // :126
+                st3(p, F_MAT_R, i, mk3(m.color[0], m.color[1], m.color[2])); // :128
+                stf(p, F_MAT_METALLIC, i, m.metallic); stf(p, F_MAT_ROUGHNESS, i, rough); // :129
+                st3(p, F_NRM_X, i, normal);                                 // :130
+                c = (m.materialType == GMUPT_MATERIAL_UE4) ? CLS_UE4 : CLS_GLASS; // :262-285 (types other than 0/1 are not produced by Scene)
+
+                // createShadowRay :135-163
+                uint32_t lightIndex = (uint32_t)(g.next() * (float)p.cam.lightCount);
+                float z = 1.0f - 2.0f * g.next();
+                float rr = dsqrt(hmax(0.0f, 1.0f - z * z));
+                float phi = 2.0f * kPi * g.next();
+                float x = rr * dcos(phi);
+                float y = rr * dsin(phi);
+                const gmupt_light L = p.scene.lights[lightIndex < GMUPT_MAX_LIGHTS ? lightIndex : GMUPT_MAX_LIGHTS - 1];
+                f3 lightPosition = mk3(L.position[0], L.position[1], L.position[2]) + mk3(x, y, z) * L.radius;
+                f3 surfacePos = ld3(p, F_SP_X, i) + normal * kEpsilonOffset;
+                f3 lightDir = lightPosition - surfacePos;
+                float distance = length3(lightDir);
+                lightDir = normalize3(lightDir);
+                stu(p, F_LIGHT_IDX, i, lightIndex);
+                st3(p, F_SH_OX, i, surfacePos);
+                st3(p, F_SH_DX, i, lightDir);
+                stf(p, F_LIGHT_DIST, i, distance - kEpsilonOffset);
+
+                st3(p, F_RAD_R, i, radiance);                               // :295
+                st3(p, F_THR_R, i, throughput);                             // :296
+                stu(p, F_PATH_LEN, i, pl + 1u);                              // :293,297
+                stu(p, F_IN_SHADOW, i, 1u);                                 // :298
+            }
+            p.cls[i] = (uint8_t)c;
+        }
+    }
+    publish_block_counts(p, c);
+}
+
+// ------------------------------------------------------------------------------------------------ k_scan
+// One workgroup.  Exclusive scan of the per-block class counts, then the counter hand-over the reference does in
+// newPath.hlsl:55-60 (extension-queue offsets, shadow counter reset).
+__global__ __launch_bounds__(1024) void k_scan(RenderParams p, int clearFrame)
+{
+    __shared__ uint32_t s_part[1024];
+    __shared__ uint32_t s_total[3];
+    const uint32_t t = threadIdx.x;
+    const uint32_t chunk = (p.nBlocks + 1023u) / 1024u;
+    const uint32_t lo = t * chunk, hi = (lo + chunk < p.nBlocks) ? lo + chunk : p.nBlocks;
+    for (int k = 0; k < 3; k++) {
+        uint32_t sum = 0;
+        for (uint32_t b = lo; b < hi; b++) sum += p.blockCounts[k * p.nBlocks + b];
+        s_part[t] = sum;
+        __syncthreads();
+        // Hillis-Steele inclusive scan over the 1024 partial sums
+        for (uint32_t off = 1; off < 1024; off <<= 1) {
+            uint32_t v = (t >= off) ? s_part[t - off] : 0u;
+            __syncthreads();
+            s_part[t] += v;
+            __syncthreads();
+        }
+        uint32_t run = s_part[t] - sum; // exclusive prefix of this thread's chunk
+        for (uint32_t b = lo; b < hi; b++) { uint32_t cnt = p.blockCounts[k * p.nBlocks + b]; p.blockOffsets[k * p.nBlocks + b] = run; run += cnt; }
+        if (t == 1023) s_total[k] = s_part[1023];
+        __syncthreads();
+    }
+    if (t == 0) {
+        const uint32_t nUE4 = s_total[CLS_UE4], nGlass = s_total[CLS_GLASS], nEnded = s_total[CLS_ENDED];
+        const uint32_t qc0 = clearFrame ? p.P : nEnded;            // logic.hlsl:178 stores PATHCOUNT on a clear
+        const uint32_t nNew = qc0 < p.L ? qc0 : p.L;               // newPath.hlsl:21-25 reaches at most the live slots
+        const uint32_t lastPath = p.qc[QC_LASTPATHCNT];
+        p.qc[QC_NEWPATH] = qc0;
+        p.qc[QC_MATUE4] = nUE4;
+        p.qc[QC_MATGLASS] = nGlass;
+        p.qc[QC_EXT_UE4_OFFSET] = qc0;                              // newPath.hlsl:57
+        p.qc[QC_EXT_GLASS_OFFSET] = qc0 + nUE4;                     // newPath.hlsl:58
+        p.qc[QC_SHADOWRAY] = 0;                                     // newPath.hlsl:59
+        p.qc[QC_EXT_COUNT] = nNew + nUE4 + nGlass;
+        uint32_t gen = nNew;
+        if (p.budget) { uint32_t remaining = p.budget > lastPath ? p.budget - lastPath : 0u; if (gen > remaining) gen = remaining; }
+        DevStats* st = p.stats;
+        if (clearFrame) st->activePaths = p.L;
+        st->activePaths -= (nNew - gen);
+        st->pathsGenerated += gen;
+        if (!clearFrame) { st->pathsCompleted += nEnded; st->segments += (unsigned long long)nEnded + nUE4 + nGlass; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ material stages
+struct Ue4State { f3 rayDir; f3 baseColor; float metallic, roughness; f3 normal; };
+
+__device__ __forceinline__ f3 ue4Sample(const Ue4State& st, Rng& g) // materialUE4.hlsl:24-68
+{
+    const f3 N = st.normal;
+    const f3 V = neg3(st.rayDir);
+    const float r0 = g.next(), r1 = g.next();                               // :29
+    const float diffuseRatio = 1.0f - st.metallic;                          // :31
+    const f3 up = dabs(N.z) < 0.999f ? mk3(0.0f, 0.0f, 1.0f) : mk3(1.0f, 0.0f, 0.0f); // :35
+    const f3 tangent = normalize3(cross3(up, N));                           // :36
+    const f3 bitangent = cross3(N, tangent);                                // :37
+    f3 direction;
+    if (g.next() < diffuseRatio) {                                          // :40
+        float x = dsqrt(r0);
+        float phi = 2.0f * kPi * r1;
+        float dx = x * dcos(phi);
+        float dy = x * dsin(phi);
+        float dz = dsqrt(hmax(0.0f, 1.0f - dx * dx - dy * dy));
+        direction = (tangent * dx + bitangent * dy) + N * dz;               // :48
+    } else {
+        float a = st.roughness * st.roughness;                              // :52
+        float phi = 2.0f * kPi * r0;
+        float cosTheta = dsqrt((1.0f - r1) / (1.0f + (a * a - 1.0f) * r1)); // :55
+        float sinTheta = dsqrt(1.0f - cosTheta * cosTheta);
+        float hx = sinTheta * dcos(phi);
+        float hy = sinTheta * dsin(phi);
+        float hz = cosTheta;
+        direction = (tangent * hx + bitangent * hy) + N * hz;               // :63
+        direction = direction * (2.0f * dot3(V, direction)) - V;            // :64
+    }
+    return direction;
+}
+
+__device__ __forceinline__ float ue4Pdf(const Ue4State& st, f3 direction) // materialUE4.hlsl:70-90
+{
+    const f3 N = st.normal, V = neg3(st.rayDir), L = direction;
+    const float diffuseRatio = 1.0f - st.metallic;
+    const float specularRatio = 1.0f - diffuseRatio;
+    const f3 H = normalize3(L + V);
+    const float NdotH = dabs(dot3(N, H));
+    const float pdfGGXTR = GGXTrowbridgeReitz(NdotH, st.roughness * st.roughness) * NdotH;
+    const float pdfSpec = pdfGGXTR / (4.0f * dabs(dot3(V, H)));
+    const float pdfDiff = dabs(dot3(L, N)) * (1.0f / kPi);
+    return diffuseRatio * pdfDiff + specularRatio * pdfSpec;
+}
+
+__device__ __forceinline__ f3 ue4Evaluate(const Ue4State& st, f3 direction) // materialUE4.hlsl:92-115
+{
+    const f3 N = st.normal, V = neg3(st.rayDir), L = direction;
+    const float NdotL = dot3(N, L), NdotV = dot3(N, V);
+    if (NdotL <= 0.0f || NdotV <= 0.0f) return mk3(0.0f, 0.0f, 0.0f);
+    const f3 H = normalize3(L + V);
+    const float NdotH = dot3(N, H), LdotH = dot3(L, H);
+    const float D = GGXTrowbridgeReitz(NdotH, st.roughness * st.roughness);
+    const float G = smithSchlickGGX(NdotL, st.roughness) * smithSchlickGGX(NdotV, st.roughness);
+    const f3 sc = mk3(0.037f + st.metallic * (st.baseColor.x - 0.037f),
+                      0.037f + st.metallic * (st.baseColor.y - 0.037f),
+                      0.037f + st.metallic * (st.baseColor.z - 0.037f));    // :110 lerp
+    const float w = 1.0f - LdotH;
+    const float w2 = w * w;
+    const float fc = w2 * w2 * w;                                            // :111 pow(1 - LdotH, 5)
+    const f3 F = mk3((1.0f - fc) * sc.x + fc, (1.0f - fc) * sc.y + fc, (1.0f - fc) * sc.z + fc);
+    const float den = 4.0f * NdotL * NdotV;
+    const float om = 1.0f - st.metallic;
+    return mk3((st.baseColor.x / kPi) * om + (D * F.x * G) / den,
+               (st.baseColor.y / kPi) * om + (D * F.y * G) / den,
+               (st.baseColor.z / kPi) * om + (D * F.z * G) / den);           // :114
+}
+
+__device__ __forceinline__ void stage_ue4(const RenderParams& p, uint32_t queueIndex, uint32_t index) // materialUE4.hlsl:118-192
+{
+    Rng g; g.seed(queueIndex, p.cam.randomSeed[0], p.cam.randomSeed[1]);   // :131
+    Ue4State st;
+    st.rayDir = ld3(p, F_RAY_DX, index);
+    st.normal = ld3(p, F_NRM_X, index);
+    st.baseColor = ld3(p, F_MAT_R, index);
+    st.metallic = ldf(p, F_MAT_METALLIC, index);
+    st.roughness = ldf(p, F_MAT_ROUGHNESS, index);
+
+    const f3 bsdfDir = ue4Sample(st, g);                                     // :148
+    const float pdf = ue4Pdf(st, bsdfDir);                                   // :149
+    f3 throughput = mk3(0.0f, 0.0f, 0.0f);
+    if (pdf > 0.0f) {                                                        // :151-152
+        const f3 e = ue4Evaluate(st, bsdfDir);
+        const float an = dabs(dot3(st.normal, bsdfDir));
+        throughput = mk3(e.x * an / pdf, e.y * an / pdf, e.z * an / pdf);
+    }
+    st3(p, F_LTHR_R, index, throughput);                                     // :154
+    const f3 surfacePoint = ld3(p, F_SP_X, index);                           // :157
+    st3(p, F_RAY_OX, index, surfacePoint + bsdfDir * kEpsilonOffset);        // :158,160
+    st3(p, F_RAY_DX, index, bsdfDir);                                        // :161
+    p.queues[(size_t)Q_EXT_RAY * p.P + p.qc[QC_EXT_UE4_OFFSET] + queueIndex] = index; // :162
+
+    const f3 lightDir = ld3(p, F_SH_DX, index);                              // :165
+    if (dot3(lightDir, st.normal) > 0.0f) {                                  // :167,178
+        const uint32_t lightIndex = ldu(p, F_LIGHT_IDX, index);
+        const float distance = ldf(p, F_LIGHT_DIST, index);
+        const gmupt_light L = p.scene.lights[lightIndex < GMUPT_MAX_LIGHTS ? lightIndex : GMUPT_MAX_LIGHTS - 1];
+        const float lightPdf = distance * distance / (4.0f * kPi * L.radius * L.radius); // :184
+        const float bsdfPdf = ue4Pdf(st, lightDir);                          // :185
+        const float ph = powerHeuristic(lightPdf, bsdfPdf);
+        const f3 e = ue4Evaluate(st, lightDir);
+        const float lc = (float)p.cam.lightCount;
+        const float fo = lightFalloff(distance, L.falloff);
+        st3(p, F_DL_R, index, mk3(ph * e.x * L.emission[0] * lc * fo, ph * e.y * L.emission[1] * lc * fo, ph * e.z * L.emission[2] * lc * fo)); // :187-188
+        // shadow queue: its order does not influence any result (shadowRayCast has no RNG), so a plain atomic
+        // (hipcc aggregates it to one add per wave) replaces the ballot + lane-0 InterlockedAdd of :168-176
+        const uint32_t pos = atomicAdd(&p.qc[QC_SHADOWRAY], 1u);
+        p.queues[(size_t)Q_SHADOW_RAY * p.P + pos] = index;                  // :189
+    }
+}
+
+__device__ __forceinline__ void stage_glass(const RenderParams& p, uint32_t queueIndex, uint32_t index) // materialGlass.hlsl:23-85
+{
+    Rng g; g.seed(queueIndex, p.cam.randomSeed[0], p.cam.randomSeed[1]);   // :61
+    const f3 rayDir = ld3(p, F_RAY_DX, index);
+    const f3 stNormal = ld3(p, F_NRM_X, index);
+    const f3 baseColor = ld3(p, F_MAT_R, index);
+
+    const f3 normal = dot3(stNormal, rayDir) <= 0.0f ? stNormal : stNormal * -1.0f; // :25
+    const float n1 = 1.0f, n2 = 1.458f;
+    float r0 = (n1 - n2) / (n1 + n2);
+    r0 = r0 * r0;
+    const float theta = dot3(neg3(rayDir), normal);                          // :34
+    const float probability = schlickFresnel(r0, theta);                     // :36
+    const float eta = dot3(stNormal, normal) > 0.0f ? (n1 / n2) : (n2 / n1); // :38
+    // refract(i, n, eta) (HLSL intrinsic)
+    const float dn = dot3(normal, rayDir);
+    const float k = 1.0f - eta * eta * (1.0f - dn * dn);
+    f3 refr = mk3(0.0f, 0.0f, 0.0f);
+    if (!(k < 0.0f)) refr = rayDir * eta - normal * (eta * dn + dsqrt(k));
+    const f3 transDirection = normalize3(refr);                              // :39
+    const float cos2t = 1.0f - eta * eta * (1.0f - theta * theta);           // :40
+    const float rnd = g.next();                                              // :42 (|| does not short-circuit in HLSL)
+    f3 bsdfDir = transDirection;
+    if (cos2t < 0.0f || rnd < probability)
+        bsdfDir = normalize3(rayDir - normal * (2.0f * dot3(normal, rayDir))); // :43 reflect
+
+    st3(p, F_LTHR_R, index, baseColor);                                      // :75
+    const f3 surfacePoint = ld3(p, F_SP_X, index);
+    st3(p, F_RAY_OX, index, surfacePoint + bsdfDir * kEpsilonOffset);        // :79,81
+    st3(p, F_RAY_DX, index, bsdfDir);                                        // :82
+    p.queues[(size_t)Q_EXT_RAY * p.P + p.qc[QC_EXT_GLASS_OFFSET] + queueIndex] = index; // :83
+}
+
+// running-mean update of one pixel for all paths that ended on it this iteration, in ascending slot order
+// (canonical schedule of logic.hlsl:57-73; the reference's unsynchronised read-modify-write loses samples instead)
+__device__ __forceinline__ void accumulate_pixel(const RenderParams& p, uint32_t pix, uint32_t head)
+{
+    float4 px = p.fb[pix];
+    uint32_t n = __builtin_bit_cast(uint32_t, px.w);
+    long long last = -1;
+    for (;;) {
+        uint32_t best = kListEnd;
+        for (uint32_t s = head; s != kListEnd; s = p.listNext[s])
+            if ((long long)s > last && s < best) best = s;
+        if (best == kListEnd) break;
+        const float r = p.sample[best], gch = p.sample[(size_t)p.P + best], b = p.sample[(size_t)2 * p.P + best];
+        const float n0 = (float)n;
+        n++;
+        const float n1 = (float)n;
+        px.x = (px.x * n0 + r) / n1;                                         // logic.hlsl:73
+        px.y = (px.y * n0 + gch) / n1;
+        px.z = (px.z * n0 + b) / n1;
+        last = (long long)best;
+    }
+    px.w = __builtin_bit_cast(float, n);
+    p.fb[pix] = px;
+    p.listHead[pix] = kListEnd;
+}
+
+__device__ __forceinline__ void stage_new_path(const RenderParams& p, uint32_t queueIndex, uint32_t index, int clearFrame) // newPath.hlsl:14-61
+{
+    if (!clearFrame) {
+        const uint32_t pix = pixel_index(p, ldu(p, F_SCR_X, index), ldu(p, F_SCR_Y, index));
+        if (pix != kListEnd && p.listHead[pix] == index) accumulate_pixel(p, pix, index);
+    }
+    const uint32_t lastPath = p.qc[QC_LASTPATHCNT];                          // :19
+    p.queues[(size_t)Q_NEWPATH * p.P + queueIndex] = index;                  // logic.hlsl:75
+    if (p.budget && (uint32_t)(lastPath + queueIndex) >= p.budget) {         // extension: retire instead of regenerating
+        p.cls[index] = CLS_RETIRED;
+        p.queues[(size_t)Q_EXT_RAY * p.P + queueIndex] = kQueueHole;
+        return;
+    }
+    Rng g; g.seed(queueIndex, p.cam.randomSeed[0], p.cam.randomSeed[1]);   // :27
+    const uint32_t w = p.tileEnabled ? p.fbW : cam_width(p.cam), h = p.tileEnabled ? p.fbH : cam_height(p.cam);
+    const uint32_t newIndex = (lastPath + queueIndex) % (w * h);             // :33
+    const uint32_t cx = (p.tileEnabled ? p.tileX0 : 0u) + newIndex % w, cy = (p.tileEnabled ? p.tileY0 : 0u) + newIndex / w; // :34
+    const float jx = g.next() * 2.0f - 1.0f;                                 // :36
+    const float jy = g.next() * 2.0f - 1.0f;
+    const float u = ((float)cx + jx) * p.cam.pixelSize[0];                   // :37
+    const float v = ((float)cy + jy) * p.cam.pixelSize[1];
+    const f3 ulc = mk3(p.cam.upperLeftCorner[0], p.cam.upperLeftCorner[1], p.cam.upperLeftCorner[2]);
+    const f3 hor = mk3(p.cam.horizontal[0], p.cam.horizontal[1], p.cam.horizontal[2]);
+    const f3 ver = mk3(p.cam.vertical[0], p.cam.vertical[1], p.cam.vertical[2]);
+    const f3 dir = normalize3((ulc + hor * u) - ver * v);                    // :39
+    st3(p, F_RAY_OX, index, mk3(p.cam.position[0], p.cam.position[1], p.cam.position[2])); // :41
+    st3(p, F_RAY_DX, index, dir);                                            // :42
+    stu(p, F_SCR_X, index, cx); stu(p, F_SCR_Y, index, cy);                  // :43
+    st3(p, F_RAD_R, index, mk3(0.0f, 0.0f, 0.0f));                           // :44
+    st3(p, F_THR_R, index, mk3(1.0f, 1.0f, 1.0f));                           // :45
+    st3(p, F_LTHR_R, index, mk3(1.0f, 1.0f, 1.0f));                          // :46
+    stu(p, F_PATH_LEN, index, 0u);                                           // :47
+    stu(p, F_IN_SHADOW, index, 1u);                                          // :48
+    p.queues[(size_t)Q_EXT_RAY * p.P + queueIndex] = index;                  // :51
+}
+
+__global__ __launch_bounds__(kBlock) void k_material(RenderParams p, int clearFrame)
+{
+    __shared__ uint32_t s_cnt[3][kBlock / 64];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t wave = threadIdx.x >> 6;
+    const int c = (i < p.L) ? (int)p.cls[i] : (int)CLS_NONE;
+    const unsigned long long b0 = __ballot(c == CLS_UE4), b1 = __ballot(c == CLS_GLASS), b2 = __ballot(c == CLS_ENDED);
+    if ((threadIdx.x & 63) == 0) { s_cnt[0][wave] = __popcll(b0); s_cnt[1][wave] = __popcll(b1); s_cnt[2][wave] = __popcll(b2); }
+    __syncthreads();
+    if (c > CLS_ENDED) return;
+    // rank = slots of the same class with a smaller index: block offset + earlier waves + lower lanes
+    const unsigned long long mine = (c == CLS_UE4) ? b0 : (c == CLS_GLASS) ? b1 : b2;
+    uint32_t rank = p.blockOffsets[c * p.nBlocks + blockIdx.x] + prefix_rank(mine);
+    for (uint32_t w = 0; w < wave; w++) rank += s_cnt[c][w];
+
+    if (c == CLS_ENDED) stage_new_path(p, rank, i, clearFrame);
+    else {
+        p.queues[(size_t)(c == CLS_UE4 ? Q_MAT_UE4 : Q_MAT_GLASS) * p.P + rank] = i; // logic.hlsl:282-285
+        if (c == CLS_UE4) stage_ue4(p, rank, i); else stage_glass(p, rank, i);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ ray casts
+// rayAABBIntersection: extensionRayCast.hlsl:79-94 == shadowRayCast.hlsl:49-63
+__device__ __forceinline__ float ray_aabb(float4 mn, float4 mx, f3 o, f3 invdir)
+{
+    const float fx = (mx.x - o.x) * invdir.x, fy = (mx.y - o.y) * invdir.y, fz = (mx.z - o.z) * invdir.z;
+    const float nx = (mn.x - o.x) * invdir.x, ny = (mn.y - o.y) * invdir.y, nz = (mn.z - o.z) * invdir.z;
+    const float tmaxx = hmax(fx, nx), tmaxy = hmax(fy, ny), tmaxz = hmax(fz, nz);
+    const float tminx = hmin(fx, nx), tminy = hmin(fy, ny), tminz = hmin(fz, nz);
+    const float t1 = hmin(tmaxx, hmin(tmaxy, tmaxz));
+    const float t0 = hmax(tminx, hmax(tminy, tminz));
+    return (t1 >= t0) ? (t0 > 0.0f ? t0 : t1) : -1.0f;
+}
+
+constexpr int kTravBlock = 256;
+constexpr int kLdsStack = 24;   // entries per lane kept in LDS; deeper entries spill to a global overflow array
+constexpr int kMaxStack = 64;   // SBVH depth limit (Include/Nvidia-SBVH/SplitBVHBuilder.h:38)
+
+struct TravStack {
+    int* lds;       // s_stack + threadIdx.x, stride kTravBlock
+    int* ovf;       // global overflow + global thread id, stride ovfStride
+    uint32_t ovfStride;
+    uint32_t ptr;
+    __device__ __forceinline__ void push(int v, DevStats* st)
+    {
+        if (ptr < kLdsStack) lds[ptr * kTravBlock] = v;
+        else if (ptr < kMaxStack) ovf[(size_t)(ptr - kLdsStack) * ovfStride] = v;
+        else st->stackOverflow = 1u;
+        ptr++;
+    }
+    __device__ __forceinline__ int pop()
+    {
+        if (ptr == 0) return -1;   // the reference's sentinel stack[0] = -1 (extensionRayCast.hlsl:100)
+        --ptr;
+        if (ptr < kLdsStack) return lds[ptr * kTravBlock];
+        if (ptr < kMaxStack) return ovf[(size_t)(ptr - kLdsStack) * ovfStride];
+        return -1;
+    }
+};
+
+struct TravCount { uint32_t inner, leaves, tris; };
+
+struct ExtHit { f3 hitPoint, bary; int4 tri; };
+
+__device__ __forceinline__ f3 load_vertex(const float* verts, int idx) { const float* v = verts + 3 * (size_t)idx; return mk3(v[0], v[1], v[2]); }
+
+// extensionRayCast.hlsl:96-166 + rayTriangleIntersection :38-77
+template <bool STATS>
+__device__ __forceinline__ float bvh_closest(const SceneView& sc, f3 o, f3 d, ExtHit& hit, TravStack& stk, DevStats* dst, TravCount& tc)
+{
+    float distance = kFltMax;
+    const f3 invdir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    stk.ptr = 0;
+    const DNode root = sc.nodes[0];
+    if (!(ray_aabb(root.mn, root.mx, o, invdir) > 0.0f)) return distance;
+    int4 link = root.link;
+    for (;;) {
+        if (link.z) { // leaf
+            if (STATS) tc.leaves++;
+            for (int i = link.x; i < link.y; i++) {
+                const int4 T = *reinterpret_cast<const int4*>(&sc.tris[i]);
+                const f3 v0 = load_vertex(sc.verts, T.x), v1 = load_vertex(sc.verts, T.y), v2 = load_vertex(sc.verts, T.z);
+                if (STATS) tc.tris++;
+                const f3 e1 = v1 - v0, e2 = v2 - v0;
+                const f3 pvec = cross3(d, e2);
+                const float det = dot3(e1, pvec);
+                if (det > -kEpsilon && det < kEpsilon) continue;
+                const float invDet = 1.0f / det;
+                const f3 tvec = o - v0;
+                const float u = dot3(tvec, pvec) * invDet;
+                if (u < 0.0f || u > 1.0f) continue;
+                const f3 qvec = cross3(tvec, e1);
+                const float v = dot3(d, qvec) * invDet;
+                if (v < 0.0f || u + v > 1.0f) continue;
+                const float t = dot3(e2, qvec) * invDet;
+                if (t >= 0.0f && t < distance) {
+                    distance = t;
+                    hit.hitPoint = o + d * t;
+                    hit.bary = mk3(1.0f - u - v, u, v);
+                    hit.tri = T;
+                }
+            }
+        } else {
+            if (STATS) tc.inner++;
+            const DNode left = sc.nodes[link.x];
+            const DNode right = sc.nodes[link.y];
+            const float leftHit = ray_aabb(left.mn, left.mx, o, invdir);
+            const float rightHit = ray_aabb(right.mn, right.mx, o, invdir);
+            if (leftHit > 0.0f && rightHit > 0.0f) {
+                if (leftHit > rightHit) { stk.push(link.x, dst); link = right.link; }
+                else { stk.push(link.y, dst); link = left.link; }
+                continue;
+            } else if (leftHit > 0.0f) { link = left.link; continue; }
+            else if (rightHit > 0.0f) { link = right.link; continue; }
+        }
+        const int idx = stk.pop();
+        if (idx < 0) break;
+        link = sc.nodes[idx].link;
+    }
+    return distance;
+}
+
+// shadowRayCast.hlsl:65-136 + rayTriangleIntersection :16-47
+template <bool STATS>
+__device__ __forceinline__ bool bvh_any(const SceneView& sc, f3 o, f3 d, float lightDistance, TravStack& stk, DevStats* dst, TravCount& tc)
+{
+    const f3 invdir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    stk.ptr = 0;
+    const DNode root = sc.nodes[0];
+    if (!(ray_aabb(root.mn, root.mx, o, invdir) > 0.0f)) return false;
+    int4 link = root.link;
+    for (;;) {
+        if (link.z) {
+            if (STATS) tc.leaves++;
+            for (int i = link.x; i < link.y; i++) {
+                const int4 T = *reinterpret_cast<const int4*>(&sc.tris[i]);
+                const f3 v0 = load_vertex(sc.verts, T.x), v1 = load_vertex(sc.verts, T.y), v2 = load_vertex(sc.verts, T.z);
+                if (STATS) tc.tris++;
+                const f3 e1 = v1 - v0, e2 = v2 - v0;
+                const f3 pvec = cross3(d, e2);
+                const float det = dot3(e1, pvec);
+                if (det > -kEpsilon && det < kEpsilon) continue;
+                const float invDet = 1.0f / det;
+                const f3 tvec = o - v0;
+                const float u = dot3(tvec, pvec) * invDet;
+                if (u < 0.0f || u > 1.0f) continue;
+                const f3 qvec = cross3(tvec, e1);
+                const float v = dot3(d, qvec) * invDet;
+                if (v < 0.0f || u + v > 1.0f) continue;
+                const float t = dot3(e2, qvec) * invDet;
+                if (t > kEpsilon && t < 1.0f / kEpsilon) {
+                    const float dist = length3(d * t);
+                    if (dist < lightDistance) return true;
+                }
+            }
+        } else {
+            if (STATS) tc.inner++;
+            const DNode left = sc.nodes[link.x];
+            const DNode right = sc.nodes[link.y];
+            const float leftHit = ray_aabb(left.mn, left.mx, o, invdir);
+            const float rightHit = ray_aabb(right.mn, right.mx, o, invdir);
+            if (leftHit > 0.0f && rightHit > 0.0f) {
+                if (leftHit > rightHit) { stk.push(link.x, dst); link = right.link; }
+                else { stk.push(link.y, dst); link = left.link; }
+                continue;
+            } else if (leftHit > 0.0f) { link = left.link; continue; }
+            else if (rightHit > 0.0f) { link = right.link; continue; }
+        }
+        const int idx = stk.pop();
+        if (idx < 0) break;
+        link = sc.nodes[idx].link;
+    }
+    return false;
+}
+
+__device__ __forceinline__ void flush_counts(DevStats* st, const TravCount& tc, uint32_t rays, bool ext)
+{
+    // wave reduction, one atomic per wave and counter
+    uint32_t a = tc.inner, b = tc.leaves, c = tc.tris, r = rays;
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); c += __shfl_down(c, off); r += __shfl_down(r, off); }
+    if ((threadIdx.x & 63) == 0) {
+        if (ext) { atomicAdd(&st->extInner, (unsigned long long)a); atomicAdd(&st->extLeaves, (unsigned long long)b); atomicAdd(&st->extTris, (unsigned long long)c); atomicAdd(&st->extRays, (unsigned long long)r); }
+        else { atomicAdd(&st->shInner, (unsigned long long)a); atomicAdd(&st->shLeaves, (unsigned long long)b); atomicAdd(&st->shTris, (unsigned long long)c); atomicAdd(&st->shRays, (unsigned long long)r); }
+    }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kTravBlock) void k_extend(RenderParams p)
+{
+    __shared__ int s_stack[kLdsStack * kTravBlock];
+    const uint32_t gtid = blockIdx.x * kTravBlock + threadIdx.x;
+    const uint32_t stride = gridDim.x * kTravBlock;
+    TravStack stk; stk.lds = s_stack + threadIdx.x; stk.ovf = p.ovfStack + gtid; stk.ovfStride = p.ovfStride; stk.ptr = 0;
+    TravCount tc = { 0, 0, 0 }; uint32_t rays = 0;
+    const uint32_t count = p.qc[QC_EXT_COUNT];
+    const uint32_t* qExt = p.queues + (size_t)Q_EXT_RAY * p.P;
+    for (uint32_t q = gtid; q < count; q += stride) {
+        const uint32_t index = qExt[q];                                      // extensionRayCast.hlsl:210
+        if (index == kQueueHole) continue;
+        const f3 o = ld3(p, F_RAY_OX, index), d = ld3(p, F_RAY_DX, index);   // :213-214
+        ExtHit hit; hit.hitPoint = mk3(0, 0, 0); hit.bary = mk3(0, 0, 0); hit.tri = make_int4(0, 0, 0, 0);
+        float distance = bvh_closest<STATS>(p.scene, o, d, hit, stk, p.stats, tc); // :216
+        if (STATS) rays++;
+        if (distance < kFltMax) {                                            // :218-225
+            st3(p, F_SP_X, index, hit.hitPoint);
+            st3(p, F_BARY_X, index, hit.bary);
+            stu(p, F_TRI_0, index, (uint32_t)hit.tri.x); stu(p, F_TRI_1, index, (uint32_t)hit.tri.y);
+            stu(p, F_TRI_2, index, (uint32_t)hit.tri.z); stu(p, F_TRI_MAT, index, (uint32_t)hit.tri.w);
+        }
+        // rayLightIntersection :168-194
+        uint32_t lightIndex = 0;
+        const uint32_t lc = p.cam.lightCount < GMUPT_MAX_LIGHTS ? p.cam.lightCount : GMUPT_MAX_LIGHTS;
+        for (uint32_t li = 0; li < lc; li++) {
+            const gmupt_light L = p.scene.lights[li];
+            const f3 position = mk3(L.position[0], L.position[1], L.position[2]) - o;
+            const float radius2 = L.radius * L.radius;
+            const float tca = dot3(position, d);
+            const float d2 = dot3(position, position) - tca * tca;
+            if (d2 > radius2) continue;
+            const float thc = dsqrt(radius2 - d2);
+            float t0 = tca - thc;
+            const float t1 = tca + thc;
+            if (t0 < 0.0f) t0 = t1;
+            if (t0 > 0.0f && t0 < distance) { distance = t0; lightIndex = li + 1; }
+        }
+        stu(p, F_IS_EMITTER, index, lightIndex);                             // :231
+        stf(p, F_HIT_DIST, index, distance);                                 // :232
+    }
+    if (STATS) flush_counts(p.stats, tc, rays, true);
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kTravBlock) void k_shadow(RenderParams p)
+{
+    __shared__ int s_stack[kLdsStack * kTravBlock];
+    const uint32_t gtid = blockIdx.x * kTravBlock + threadIdx.x;
+    const uint32_t stride = gridDim.x * kTravBlock;
+    const uint32_t count = p.qc[QC_SHADOWRAY];                               // shadowRayCast.hlsl:151
+    __syncthreads();
+    if (gtid == 0) {
+        // :144-148: QC[0..3] = (0, QC1 + QC0, 0, 0).  Nothing else in this kernel reads those words.
+        const uint32_t q0 = p.qc[QC_NEWPATH], q1 = p.qc[QC_LASTPATHCNT];
+        p.qc[QC_NEWPATH] = 0; p.qc[QC_LASTPATHCNT] = q0 + q1; p.qc[QC_MATUE4] = 0; p.qc[QC_MATGLASS] = 0;
+    }
+    TravStack stk; stk.lds = s_stack + threadIdx.x; stk.ovf = p.ovfStack + gtid; stk.ovfStride = p.ovfStride; stk.ptr = 0;
+    TravCount tc = { 0, 0, 0 }; uint32_t rays = 0;
+    const uint32_t* qSh = p.queues + (size_t)Q_SHADOW_RAY * p.P;
+    for (uint32_t q = gtid; q < count; q += stride) {
+        const uint32_t index = qSh[q];                                       // :159
+        const f3 o = ld3(p, F_SH_OX, index), d = ld3(p, F_SH_DX, index);     // :162-163
+        const float lightDistance = ldf(p, F_LIGHT_DIST, index);             // :164
+        const bool inShadow = bvh_any<STATS>(p.scene, o, d, lightDistance, stk, p.stats, tc); // :166
+        if (STATS) rays++;
+        stu(p, F_IN_SHADOW, index, inShadow ? 1u : 0u);                      // :167
+    }
+    if (STATS) flush_counts(p.stats, tc, rays, false);
+}
+
+// ------------------------------------------------------------------------------------------------ detmath probe
+__global__ void k_detmath(int fn, const float* x, const float* y, float* out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r = 0.0f;
+    switch (fn) {
+    case 0: r = dsin(x[i]); break;
+    case 1: r = dcos(x[i]); break;
+    case 2: r = dlog2(x[i]); break;
+    case 3: r = dexp2(x[i]); break;
+    case 4: r = dpow(x[i], y[i]); break;
+    case 5: r = dfrac(x[i]); break;
+    case 6: { Rng g; g.seed((uint32_t)x[i], y[i], y[i] * 0.5f); g.next(); r = g.next(); } break;
+    default: break;
+    }
+    out[i] = r;
+}
+
+// ------------------------------------------------------------------------------------------------ host launchers
+static inline uint32_t slot_blocks(const RenderParams& p) { return p.nBlocks; }
+
+void launch_clear(const RenderParams& p, hipStream_t s) { hipLaunchKernelGGL(k_clear, dim3(slot_blocks(p)), dim3(kBlock), 0, s, p); }
+void launch_logic(const RenderParams& p, hipStream_t s) { hipLaunchKernelGGL(k_logic, dim3(slot_blocks(p)), dim3(kBlock), 0, s, p); }
+void launch_scan(const RenderParams& p, int clearFrame, hipStream_t s) { hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, p, clearFrame); }
+void launch_material(const RenderParams& p, int clearFrame, hipStream_t s) { hipLaunchKernelGGL(k_material, dim3(slot_blocks(p)), dim3(kBlock), 0, s, p, clearFrame); }
+void launch_extend(const RenderParams& p, uint32_t blocks, bool stats, hipStream_t s)
+{
+    if (stats) hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(kTravBlock), 0, s, p);
+    else hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(kTravBlock), 0, s, p);
+}
+void launch_shadow(const RenderParams& p, uint32_t blocks, bool stats, hipStream_t s)
+{
+    if (stats) hipLaunchKernelGGL(k_shadow<true>, dim3(blocks), dim3(kTravBlock), 0, s, p);
+    else hipLaunchKernelGGL(k_shadow<false>, dim3(blocks), dim3(kTravBlock), 0, s, p);
+}
+void launch_detmath(int fn, const float* x, const float* y, float* out, uint32_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_detmath, dim3((n + 255) / 256), dim3(256), 0, s, fn, x, y, out, n);
+}
+uint32_t traversal_block_threads() { return kTravBlock; }
+uint32_t traversal_overflow_entries() { return kMaxStack - kLdsStack; }
+
+} // namespace gmupt

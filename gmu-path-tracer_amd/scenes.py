@@ -1,0 +1,192 @@
+"""Synthetic scene generators for the BASELINE.json configurations.
+
+The reference's own assets are unresolved Git-LFS pointers (Assets/Models/*.gltf, *.bin), so the parity and
+bench scenes are generated here with fixed seeds.  A scene is a dict of numpy arrays laid out exactly as the
+reference's BVHWrapper produces them (Source/BVHWrapper.cpp:13-96): world-space float3 vertices, one
+TriangleProperties per VERTEX (smooth normal, uv, material id), triangle vertex indices, 48-byte materials,
+32-byte lights (128-entry table), plus the camera pose of the scene's .params row 0.
+"""
+import numpy as np
+
+from . import capi
+
+
+def _material(color, metallic=0.0, roughness=1.0, mtype=capi.MATERIAL_UE4):
+    m = np.zeros((), dtype=capi.material_dtype)
+    m["color"] = (color[0], color[1], color[2], 1.0)
+    m["metallic"], m["roughness"] = metallic, roughness
+    m["refractIndex"], m["transmittance"] = 1.458, 0.0
+    m["textureIndices"] = (-1, -1, -1)
+    m["materialType"] = mtype
+    return m
+
+
+def _lights(rows):
+    """rows: (x, y, z, falloff, r, g, b, radius) as in a .params file (Source/Scene.cpp:43-54)."""
+    out = np.zeros(capi.MAX_LIGHTS, dtype=capi.light_dtype)
+    for i, r in enumerate(rows):
+        out[i]["position"] = r[0:3]
+        out[i]["falloff"] = r[3]
+        out[i]["emission"] = r[4:7]
+        out[i]["radius"] = r[7]
+    return out
+
+
+DEFAULT_LIGHTS = [(13.0, 4.5, 4.5, 100.0, 80.0, 80.0, 40.0, 0.5), (0.0, 4.5, 2.0, 100.0, 80.0, 80.0, 40.0, 0.5)]  # Scene.cpp:60-61
+DEFAULT_CAMERA = (1.0, 3.0, 8.0, 0.0, 270.0)  # Scene.cpp:59
+
+
+class _MeshBuilder:
+    def __init__(self):
+        self.v, self.n, self.m, self.t = [], [], [], []
+
+    def quad(self, p0, p1, p2, p3, normal, mat):
+        base = len(self.v)
+        for p in (p0, p1, p2, p3):
+            self.v.append(p); self.n.append(normal); self.m.append(mat)
+        self.t.append((base, base + 1, base + 2)); self.t.append((base, base + 2, base + 3))
+
+    def box(self, center, half, yaw_deg, mat):
+        c = np.asarray(center, np.float64); h = np.asarray(half, np.float64)
+        a = np.deg2rad(yaw_deg); R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        def P(sx, sy, sz):
+            return tuple(c + R @ (h * np.array([sx, sy, sz])))
+        faces = [((1, 0, 0), [(1, -1, -1), (1, 1, -1), (1, 1, 1), (1, -1, 1)]), ((-1, 0, 0), [(-1, -1, 1), (-1, 1, 1), (-1, 1, -1), (-1, -1, -1)]),
+                 ((0, 1, 0), [(-1, 1, -1), (-1, 1, 1), (1, 1, 1), (1, 1, -1)]), ((0, -1, 0), [(-1, -1, 1), (-1, -1, -1), (1, -1, -1), (1, -1, 1)]),
+                 ((0, 0, 1), [(-1, -1, 1), (1, -1, 1), (1, 1, 1), (-1, 1, 1)]), ((0, 0, -1), [(1, -1, -1), (-1, -1, -1), (-1, 1, -1), (1, 1, -1)])]
+        for nrm, corners in faces:
+            n = tuple(R @ np.array(nrm, np.float64))
+            self.quad(*[P(*k) for k in corners], n, mat)
+
+    def mesh(self, verts, normals, tris, mat):
+        base = len(self.v)
+        self.v.extend(map(tuple, verts)); self.n.extend(map(tuple, normals)); self.m.extend([mat] * len(verts))
+        self.t.extend((int(a) + base, int(b) + base, int(c) + base) for a, b, c in tris)
+
+    def arrays(self):
+        return (np.asarray(self.v, np.float32), np.asarray(self.n, np.float32), np.asarray(self.m, np.uint32), np.asarray(self.t, np.int32))
+
+
+def _room(mb, lo, hi, mats, open_front=False):
+    """axis-aligned room with inward normals; mats = (floor, ceiling, back, left, right, front)"""
+    x0, y0, z0 = lo; x1, y1, z1 = hi
+    mb.quad((x0, y0, z1), (x1, y0, z1), (x1, y0, z0), (x0, y0, z0), (0, 1, 0), mats[0])
+    mb.quad((x0, y1, z0), (x1, y1, z0), (x1, y1, z1), (x0, y1, z1), (0, -1, 0), mats[1])
+    mb.quad((x0, y0, z0), (x1, y0, z0), (x1, y1, z0), (x0, y1, z0), (0, 0, 1), mats[2])
+    mb.quad((x0, y0, z1), (x0, y0, z0), (x0, y1, z0), (x0, y1, z1), (1, 0, 0), mats[3])
+    mb.quad((x1, y0, z0), (x1, y0, z1), (x1, y1, z1), (x1, y1, z0), (-1, 0, 0), mats[4])
+    if not open_front:
+        mb.quad((x1, y0, z1), (x0, y0, z1), (x0, y1, z1), (x1, y1, z1), (0, 0, -1), mats[5])
+
+
+def cornell_mesh():
+    """Config 2: 5 walls (10 tris) + 2 boxes (24 tris) = 34 triangles, room 10x10x10 centred at (0,5,0), diffuse only."""
+    mb = _MeshBuilder()
+    _room(mb, (-5, 0, -5), (5, 10, 5), (0, 0, 0, 1, 2, 0), open_front=True)
+    mb.box((-1.8, 3.0, -1.5), (1.5, 3.0, 1.5), 18.0, 0)   # tall box, rotated
+    mb.box((1.7, 1.5, 1.0), (1.5, 1.5, 1.5), -17.0, 0)    # short box
+    v, n, m, t = mb.arrays()
+    materials = np.stack([_material((0.73, 0.73, 0.73)), _material((0.65, 0.05, 0.05)), _material((0.12, 0.45, 0.15))])
+    return {"verts": v, "normals": n, "vertex_material": m, "indices": t, "materials": materials,
+            "lights": _lights(DEFAULT_LIGHTS), "light_count": 2, "camera": DEFAULT_CAMERA, "name": "cornell34"}
+
+
+def icosphere(subdiv):
+    t = (1.0 + np.sqrt(5.0)) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    v = [tuple(np.asarray(p, np.float64) / np.linalg.norm(p)) for p in v]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    for _ in range(subdiv):
+        cache, nf = {}, []
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                p = (np.asarray(v[a]) + np.asarray(v[b])) * 0.5
+                v.append(tuple(p / np.linalg.norm(p)))
+                cache[key] = len(v) - 1
+            return cache[key]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    return np.asarray(v, np.float64), np.asarray(f, np.int32)
+
+
+def spheres_mesh(n_spheres=202, subdiv=3, seed=1234, floor_quads=20, half_extent=12.0, height=10.0):
+    """Configs 3/4 (202 icospheres at subdivision 3 -> 259 372 triangles) and config 5 (1953 at subdivision 4).
+
+    Closed room (12 tris) + icospheres with shared vertices on a jittered grid, radius 0.3-0.8, + a floor_quads^2 quad
+    floor.  Materials: 60 % rough dielectric, 25 % metallic (roughness 0.1-0.6), 15 % glass; two sphere lights.
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    mb = _MeshBuilder()
+    E, H = half_extent, height
+    _room(mb, (-E, -0.05, -E), (E, H, E), (0, 0, 0, 1, 2, 0), open_front=False)
+    materials = [_material((0.7, 0.7, 0.7)), _material((0.6, 0.1, 0.1)), _material((0.1, 0.5, 0.15))]
+    # tessellated floor
+    fq = floor_quads
+    xs = np.linspace(-E, E, fq + 1)
+    for i in range(fq):
+        for j in range(fq):
+            mb.quad((xs[i], 0.0, xs[j + 1]), (xs[i + 1], 0.0, xs[j + 1]), (xs[i + 1], 0.0, xs[j]), (xs[i], 0.0, xs[j]), (0, 1, 0), 0)
+    sv, sf = icosphere(subdiv)
+    g = int(np.ceil(np.sqrt(n_spheres)))
+    cell = 2.0 * (E - 1.0) / g
+    cells = rng.permutation(g * g)[:n_spheres]
+    for k, cidx in enumerate(cells):
+        ci, cj = divmod(int(cidx), g)
+        radius = rng.uniform(0.3, 0.8) * min(1.0, cell / 1.7)
+        cx = -(E - 1.0) + (ci + 0.5) * cell + rng.uniform(-0.25, 0.25) * (cell - 2 * radius)
+        cz = -(E - 1.0) + (cj + 0.5) * cell + rng.uniform(-0.25, 0.25) * (cell - 2 * radius)
+        cy = rng.uniform(radius + 0.02, 6.0)
+        u = rng.uniform()
+        col = tuple(rng.uniform(0.25, 0.9, size=3))
+        if u < 0.60:
+            mat = _material(col, 0.0, rng.uniform(0.5, 1.0))
+        elif u < 0.85:
+            mat = _material(col, 1.0, rng.uniform(0.1, 0.6))
+        else:
+            mat = _material((0.95, 0.95, 0.95), 0.0, 0.1, capi.MATERIAL_GLASS)
+        if len(materials) < capi.MAX_LIGHTS:  # the material cbuffer holds 128 entries (logic.hlsl:8)
+            materials.append(mat); mid = len(materials) - 1
+        else:
+            mid = 3 + (k % (capi.MAX_LIGHTS - 3))
+        mb.mesh(sv * radius + np.array([cx, cy, cz]), sv, sf, mid)
+    v, n, m, t = mb.arrays()
+    lights = _lights([(-5.0, 8.0, 3.0, 100.0, 80.0, 80.0, 40.0, 0.5), (5.0, 8.0, -3.0, 100.0, 80.0, 80.0, 40.0, 0.5)])
+    return {"verts": v, "normals": n, "vertex_material": m, "indices": t, "materials": np.stack(materials),
+            "lights": lights, "light_count": 2, "camera": (0.0, 4.0, 11.0, -8.0, 270.0), "name": "spheres%d_s%d" % (n_spheres, subdiv)}
+
+
+def random_triangles_mesh(n=2000, seed=1, extent=10.0, size=1.0):
+    """Unstructured triangle soup (builder / traversal tests)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    c = rng.uniform(-extent, extent, size=(n, 1, 3))
+    v = (c + rng.uniform(-size, size, size=(n, 3, 3))).reshape(-1, 3).astype(np.float32)
+    t = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+    e1 = v[t[:, 1]] - v[t[:, 0]]; e2 = v[t[:, 2]] - v[t[:, 0]]
+    fn = np.cross(e1, e2); fn /= np.maximum(np.linalg.norm(fn, axis=1, keepdims=True), 1e-20)
+    nrm = np.repeat(fn, 3, axis=0).astype(np.float32)
+    mats = np.stack([_material((0.7, 0.7, 0.7)), _material((0.8, 0.6, 0.2), 1.0, 0.3), _material((0.95, 0.95, 0.95), 0.0, 0.1, capi.MATERIAL_GLASS)])
+    vm = np.repeat(rng.integers(0, 3, size=n).astype(np.uint32), 3)
+    return {"verts": v, "normals": nrm, "vertex_material": vm, "indices": t, "materials": mats,
+            "lights": _lights([(0.0, 14.0, 0.0, 100.0, 80.0, 80.0, 40.0, 0.5), (6.0, 3.0, 6.0, 100.0, 40.0, 80.0, 80.0, 0.7)]),
+            "light_count": 2, "camera": (0.0, 2.0, 24.0, 0.0, 270.0), "name": "soup%d" % n}
+
+
+def build_scene(mesh, sbvh_params=None):
+    """BVHWrapper::buildSBVH: host SBVH build + flatten -> the buffers Renderer::draw binds (t0-t4, b1)."""
+    built = capi.sbvh_build(mesh["verts"], mesh["indices"], mesh["vertex_material"], sbvh_params)
+    nv = mesh["verts"].shape[0]
+    props = np.zeros(nv, dtype=capi.tri_props_dtype)
+    props["normal"] = mesh["normals"]
+    props["materialID"] = mesh["vertex_material"]
+    if "uv" in mesh:
+        props["uv"] = mesh["uv"]
+    scene = {"nodes": built["nodes"], "tris": built["tris"], "verts": np.ascontiguousarray(mesh["verts"], np.float32),
+             "props": props, "lights": mesh["lights"], "materials": np.ascontiguousarray(mesh["materials"]),
+             "light_count": mesh["light_count"], "camera": mesh["camera"], "name": mesh["name"],
+             "sah": built["sah"], "depth": built["depth"], "ref_triangle": built["ref_triangle"],
+             "num_triangles": int(mesh["indices"].shape[0])}
+    return scene

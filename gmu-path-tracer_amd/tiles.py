@@ -1,0 +1,52 @@
+"""Framebuffer tile split across ranks and the gather at accumulate time.
+
+Pixels are independent, so the path shards with no data-path collective: every rank owns a private pipeline
+(pool, queues, counters, accumulation tile) and renders a horizontal row band of the frame with the GLOBAL
+camera (gmupt_renderer_desc.tile_*).  The only exchange is one gather of the disjoint tiles to rank 0 --
+torch.distributed.gather (backend "nccl" = RCCL over xGMI on MI355X, "gloo" in the CPU tests); no reduction.
+"""
+import numpy as np
+
+
+def row_bands(height, world_size):
+    """[(y0, rows)] for each rank: contiguous row bands whose sizes differ by at most one row."""
+    base, extra = divmod(height, world_size)
+    out, y = [], 0
+    for r in range(world_size):
+        rows = base + (1 if r < extra else 0)
+        out.append((y, rows))
+        y += rows
+    return out
+
+
+def tile_budget(width, rows, spp):
+    return width * rows * spp
+
+
+def assemble(tiles, width, height, world_size):
+    """Stacks per-rank row bands (each rows x width x 4 float32) into the full frame."""
+    bands = row_bands(height, world_size)
+    frame = np.zeros((height, width, 4), dtype=np.float32)
+    for (y0, rows), t in zip(bands, tiles):
+        frame[y0:y0 + rows] = np.asarray(t).reshape(-1, width, 4)[:rows]
+    return frame
+
+
+def gather_tiles(local_tile, width, height, rank, world_size, dist=None, device=None):
+    """Gathers the per-rank tiles on rank 0.  local_tile: torch tensor (rows, width, 4) float32 on `device`.
+
+    Bands may differ by one row, so every rank pads to the largest band; rank 0 returns the assembled frame
+    (numpy, height x width x 4), other ranks return None.
+    """
+    import torch
+    if world_size == 1 or dist is None:
+        return assemble([local_tile.cpu().numpy()], width, height, 1)
+    bands = row_bands(height, world_size)
+    max_rows = max(r for _, r in bands)
+    padded = torch.zeros((max_rows, width, 4), dtype=torch.float32, device=local_tile.device)
+    padded[:local_tile.shape[0]] = local_tile
+    gathered = [torch.empty_like(padded) for _ in range(world_size)] if rank == 0 else None
+    dist.gather(padded, gathered, dst=0)
+    if rank != 0:
+        return None
+    return assemble([g.cpu().numpy() for g in gathered], width, height, world_size)
