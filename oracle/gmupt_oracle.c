@@ -672,7 +672,7 @@ void orc_stage_extension(orc_renderer* r)
     uint64_t inner = 0, leaves = 0, tris = 0, rays = 0; uint32_t maxStack = r->stats.maxStack;
     int nthreads = r->cfg.threads > 1 ? (int)r->cfg.threads : 1;
     (void)nthreads;
-#pragma omp parallel for schedule(dynamic, 4096) num_threads(nthreads) reduction(+:inner,leaves,tris,rays) reduction(max:maxStack)
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads) reduction(+:inner,leaves,tris,rays) reduction(max:maxStack)
     for (uint32_t queueIndex = 0; queueIndex < count; queueIndex++) {
         uint32_t index = qExt[queueIndex];                               /* :210 */
         if (index == 0xFFFFFFFFu) continue;                              /* extension: hole left by a retired slot */
@@ -780,7 +780,7 @@ void orc_stage_shadow(orc_renderer* r)
     uint64_t inner = 0, leaves = 0, tris = 0; uint32_t maxStack = r->stats.maxStack;
     int nthreads = r->cfg.threads > 1 ? (int)r->cfg.threads : 1;
     (void)nthreads;
-#pragma omp parallel for schedule(dynamic, 4096) num_threads(nthreads) reduction(+:inner,leaves,tris) reduction(max:maxStack)
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads) reduction(+:inner,leaves,tris) reduction(max:maxStack)
     for (uint32_t queueIndex = 0; queueIndex < count; queueIndex++) {
         uint32_t index = qSh[queueIndex];                                /* :159 */
         v3 o = ld3(r, F_SHADOWRAY_ORIGIN, index), d = ld3(r, F_SHADOWRAY_DIRECTION, index); /* :162-163 */

@@ -1,0 +1,213 @@
+"""GPU parity tests: the HIP pipeline (through the C-ABI, libgmupt.so) against the CPU oracle on the same seeded inputs.
+
+Bar: BIT-EXACT path state (all 21 fields of the reference layout), queue contents, counters and RGBA32F framebuffer.
+north_star asks for per-pixel radiance within 1e-4 relative; both sides evaluate the same stated sequence of IEEE
+binary32 operations, so the tests assert equality of the bit patterns (tolerance 0 <= 1e-4).
+The oracle itself is "parity unpinned" against the DX11 reference (no golden vectors exist; see oracle/gmupt_oracle.h).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import parity_util as PU
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+REL_TOL = 1e-4  # north_star tolerance; the tests below are stricter (bitwise)
+
+
+def _assert_same(orc, hip, P, L, it, check_queues=True):
+    bad = PU.compare_state(orc, hip, P, L)
+    assert not bad, "iteration %d: path state differs: %r" % (it, bad[:4])
+    qa, qb = orc.counters(), hip.counters()
+    assert np.array_equal(qa, qb), "iteration %d: counters %r vs %r" % (it, qa.tolist(), qb.tolist())
+    fa, fb = orc.framebuffer(), hip.framebuffer()
+    assert PU.max_rel_err(fa[..., :3], fb[..., :3]) <= REL_TOL
+    assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32)), "iteration %d: framebuffer differs" % it
+    if check_queues:
+        oq, hq = orc.queues(), hip.read_queues()
+        n_ext = int(qa[7])
+        assert np.array_equal(oq[3][:n_ext], hq[3][:n_ext]), "extension queue"
+        # the shadow queue is a set: its order does not influence any result (no RNG in shadowRayCast)
+        assert sorted(oq[4][:qa[6]].tolist()) == sorted(hq[4][:qb[6]].tolist()), "shadow queue"
+
+
+def test_detmath_bit_identical(device):
+    rng = np.random.default_rng(0)
+    n = 1 << 18
+    cases = [(0, rng.uniform(-400, 400, n), None), (1, rng.uniform(-400, 400, n), None), (0, rng.uniform(-7, 7, n), None),
+             (2, np.exp(rng.uniform(-90, 3, n)), None), (3, rng.uniform(-160, 130, n), None),
+             (4, rng.uniform(0, 1, n), np.full(n, 1 / 2.2)), (5, rng.uniform(-100, 100, n), None),
+             (6, rng.integers(0, 1 << 22, n).astype(np.float32), rng.uniform(0, 1, n))]
+    for fn, x, y in cases:
+        a, b = O.detmath(fn, x, y), device.detmath(fn, x, y)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "detmath fn %d differs in %d of %d" % (fn, (a.view(np.uint32) != b.view(np.uint32)).sum(), n)
+    sp = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, 1e38, -1e-10, 3.4e38], np.float32)
+    for fn in (0, 1, 3, 5):
+        a, b = O.detmath(fn, sp), device.detmath(fn, sp)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), fn
+
+
+@pytest.mark.parametrize("scene_name,W,H,P,L,iters", [
+    ("cornell", 64, 36, 4096, 0, 30),          # config 2 at fixture size: diffuse only, 2 default lights
+    ("cornell", 32, 18, 8192, 6144, 12),       # reference quirk Q1: live < pool, 14 in-flight paths per pixel (accumulation order)
+    ("soup", 48, 27, 2048, 0, 40),             # UE4 dielectric + metal + glass, spatial-split references
+    ("spheres", 48, 27, 2048, 0, 120),         # closed room: long paths, glass spheres
+])
+def test_iteration_parity(pkg, device, cornell_scene, soup_scene, spheres_small_scene, scene_name, W, H, P, L, iters):
+    scene = {"cornell": cornell_scene, "soup": soup_scene, "spheres": spheres_small_scene}[scene_name]
+    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, scene, W, H, P, live=L)
+    live = L or P
+    for it in range(iters):
+        PU.step_both(orc, hip, ocam, hcam)
+        if it < 6 or it % 10 == 9 or it == iters - 1:
+            _assert_same(orc, hip, P, live, it)
+    so, sh = orc.stats(), hip.stats()
+    assert so.pathsEnded == sh.paths_completed and so.pathsGenerated == sh.paths_generated and so.segments == sh.segments
+    assert sh.reserved_ == 0, "traversal stack overflow flag"
+    hip.close(); sb.close(); orc.close()
+
+
+def test_traversal_statistics_match(pkg, device, soup_scene):
+    # the counting variant of the ray-cast kernels reports the same inner-node / triangle-test totals as the oracle for the
+    # extension stage (the visited set does not depend on the traversal order)
+    W, H, P = 32, 18, 1024
+    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, soup_scene, W, H, P, collect_stats=True)
+    for it in range(10):
+        PU.step_both(orc, hip, ocam, hcam)
+    _assert_same(orc, hip, P, P, 9)
+    so, sh = orc.stats(), hip.stats()
+    assert (so.extRays, so.extInner, so.extLeaves, so.extTris) == (sh.ext_rays, sh.ext_inner, sh.ext_leaves, sh.ext_tris)
+    assert so.shRays == sh.sh_rays and so.shInner == sh.sh_inner and so.shTris == sh.sh_tris
+    hip.close(); sb.close(); orc.close()
+
+
+def test_tile_and_budget_and_depth_extensions(pkg, device, cornell_scene):
+    # multi-GPU tile (global camera, local accumulation), path budget drain, max depth: bitwise vs the oracle with the same parameters
+    W, H, P = 48, 24, 2048
+    tile = (0, 8); rows = 8
+    budget = W * rows * 6
+    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, cornell_scene, W, rows, P, tile=tile, path_budget=budget, max_depth=6, full=(W, H))
+    it = 0
+    while it < 400:
+        PU.step_both(orc, hip, ocam, hcam)
+        it += 1
+        if it < 4 or it % 16 == 0:
+            _assert_same(orc, hip, P, P, it, check_queues=False)
+        if orc.active_paths() == 0:
+            break
+    assert orc.active_paths() == 0 and hip.stats().active_paths == 0, "budget did not drain"
+    _assert_same(orc, hip, P, P, it, check_queues=False)
+    fb = hip.framebuffer()
+    spp = fb[..., 3].view(np.uint32)
+    assert int(spp.sum()) == budget and np.all(spp == 6), "every pixel of the tile receives exactly 6 samples"
+    hip.close(); sb.close(); orc.close()
+
+
+def test_render_budget_helper_matches_oracle(pkg, device, soup_scene):
+    g = np.load(os.path.join(GOLDEN, "soup2000_32x18_p1024_i16_budget.npz"))
+    W, H, P, budget = int(g["width"]), int(g["height"]), int(g["pool"]), int(g["path_budget"])
+    sb = pkg.capi.SceneBuffers(device, soup_scene)
+    hip = pkg.capi.Renderer(device, W, H, pool_paths=P, path_budget=budget)
+    hip.bind_scene(sb)
+    cam = pkg.capi.Camera(W, H); cam.set_pose(*soup_scene["camera"])
+    iters = hip.render_budget(cam, 10000)
+    assert hip.stats().paths_completed == budget and iters <= int(g["iters"]) + 8
+    fb = hip.framebuffer()
+    assert np.array_equal(fb[..., 3].view(np.uint32), g["framebuffer"][..., 3].view(np.uint32))
+    # iterations past the drain point change nothing, so the golden (64 oracle iterations) is reproduced bit for bit
+    assert np.array_equal(fb.view(np.uint32), g["framebuffer"].view(np.uint32))
+    hip.close(); sb.close()
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*_i[0-9]*.npz"))), ids=lambda p: os.path.basename(p)[:-4])
+def test_golden_fixtures_on_gpu(pkg, device, path):
+    g = np.load(path)
+    name = os.path.basename(path)
+    mesh = pkg.scenes.cornell_mesh() if name.startswith("cornell") else pkg.scenes.spheres_mesh(n_spheres=12, subdiv=2, seed=7, floor_quads=4) \
+        if name.startswith("spheres12") else pkg.scenes.random_triangles_mesh(2000, seed=1)
+    scene = pkg.scenes.build_scene(mesh)
+    W, H, P = int(g["width"]), int(g["height"]), int(g["pool"])
+    sb = pkg.capi.SceneBuffers(device, scene)
+    hip = pkg.capi.Renderer(device, W, H, pool_paths=P, path_budget=int(g["path_budget"]))
+    hip.bind_scene(sb)
+    cam = pkg.capi.Camera(W, H); cam.set_pose(*scene["camera"])
+    for k in range(int(g["iters"])):
+        cam.update(0.0)
+        assert (cam.buffer.randomSeed[0], cam.buffer.randomSeed[1]) == tuple(g["seeds"][k])
+        hip.set_camera(cam.buffer); hip.iterate()
+    assert np.array_equal(hip.framebuffer().view(np.uint32), g["framebuffer"].view(np.uint32))
+    assert np.array_equal(hip.counters(), g["counters"])
+    hip.close(); sb.close()
+
+
+def test_stage_level_parity_from_frozen_state(pkg, device, spheres_small_scene):
+    # freeze an oracle state mid-render, load it into the HIP renderer and run the three stage groups one by one
+    W, H, P = 40, 24, 2048
+    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, spheres_small_scene, W, H, P)
+    for _ in range(25):
+        ocam.update(); hcam.update(0.0); orc.set_camera(ocam.buffer); orc.iterate()
+    hip.write_path_state(orc.path_state()); hip.write_queues(orc.queues()); hip.write_counters(orc.counters())
+    hip.write_framebuffer(orc.framebuffer())
+    ocam.update(); hcam.update(0.0); orc.set_camera(ocam.buffer); hip.set_camera(hcam.buffer)
+    for s in ("logic", "new_path", "material_ue4", "material_glass"):
+        orc.stage(s)
+    hip.run_stage(pkg.capi.STAGE_SHADE)
+    assert not PU.compare_state(orc, hip, P, P), "shade group (logic + newPath + materialUE4 + materialGlass)"
+    assert np.array_equal(orc.framebuffer().view(np.uint32), hip.framebuffer().view(np.uint32))
+    qa, qb = orc.counters(), hip.counters()
+    assert np.array_equal(qa[[0, 1, 2, 3, 4, 5, 6]], qb[[0, 1, 2, 3, 4, 5, 6]])
+    oq, hq = orc.queues(), hip.read_queues()
+    for q, n in ((0, qa[0]), (1, qa[2]), (2, qa[3]), (3, P)):
+        assert np.array_equal(oq[q][:n], hq[q][:n]), "queue %d" % q
+    orc.stage("extension"); hip.run_stage(pkg.capi.STAGE_EXTEND)
+    bad = PU.compare_state(orc, hip, P, P, fields=["surfacePoint", "baryCoord", "triangle", "isEmitter", "hitDistance"])
+    assert not bad, bad
+    orc.stage("shadow"); hip.run_stage(pkg.capi.STAGE_SHADOW)
+    assert not PU.compare_state(orc, hip, P, P, fields=["inShadow"])
+    assert np.array_equal(orc.counters()[:7], hip.counters()[:7])
+    hip.close(); sb.close(); orc.close()
+
+
+def test_camera_reset_resize_and_light_update(pkg, device, cornell_scene):
+    W, H, P = 32, 18, 1024
+    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, cornell_scene, W, H, P)
+    for it in range(6):
+        PU.step_both(orc, hip, ocam, hcam)
+    # accumulation reset (camera moved / shader reload): iterationCounter back to 0 => clear + regenerate (logic.hlsl:206)
+    ocam.c.cb.sampleCounter = -1; hcam.reset_accumulation()
+    for it in range(5):
+        PU.step_both(orc, hip, ocam, hcam)
+        _assert_same(orc, hip, P, P, it)
+    # light edit through gmupt_buffer_update (GUI.cpp:125-130)
+    lights = cornell_scene["lights"].copy(); lights["emission"][1] = (20.0, 60.0, 90.0); lights["position"][1] = (1.0, 6.0, 0.0)
+    sb.lights.update(lights)
+    scene2 = dict(cornell_scene); scene2["lights"] = lights
+    orc2 = O.Renderer(scene2, W, H, P)
+    orc2.path_state()[:] = orc.path_state(); orc2.queues()[:] = orc.queues(); orc2.counters()[:] = orc.counters(); orc2.framebuffer()[:] = orc.framebuffer()
+    for it in range(6):
+        PU.step_both(orc2, hip, ocam, hcam)
+    _assert_same(orc2, hip, P, P, 99)
+    # resize: new zeroed accumulation target, camera resolution update resets the counter (Renderer.cpp:408-413, Camera.cpp:22)
+    hip.resize(24, 12)
+    assert hip.framebuffer().shape == (12, 24, 4) and not hip.framebuffer().any()
+    hip.close(); sb.close(); orc.close(); orc2.close()
+
+
+def test_error_convention_on_device(pkg, device, cornell_scene):
+    capi = pkg.capi
+    r = capi.Renderer(device, 16, 16, pool_paths=256)
+    with pytest.raises(capi.GmuptError, match="no scene bound"):
+        r.iterate()
+    sb = capi.SceneBuffers(device, cornell_scene)
+    r.bind_scene(sb)
+    with pytest.raises(capi.GmuptError, match="no camera set"):
+        r.iterate()
+    with pytest.raises(capi.GmuptError):
+        capi.Buffer(device, capi.BUFFER_BVH_NODES, np.zeros(47, np.uint8))        # not a multiple of the 48-byte element
+    with pytest.raises(capi.GmuptError):
+        capi.Device(99)
+    r.close(); sb.close()
