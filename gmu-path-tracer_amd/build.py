@@ -12,7 +12,7 @@ LIB = os.path.join(HERE, "libgmupt.so")
 
 DEVICE_SOURCES = ["csrc/pt_kernels.hip", "csrc/gmupt_capi.hip"]
 HOST_SOURCES = ["host/sbvh_builder.cpp", "host/Camera.cpp"]
-HEADERS = ["csrc/pt_device.hpp", "csrc/detmath.hpp", "host/sbvh_builder.hpp", "host/Camera.hpp", "host/Constants.hpp", "../include/gmupt.h"]
+HEADERS = ["host/MeshData.hpp", "host/BVHWrapper.hpp", "csrc/pt_device.hpp", "csrc/detmath.hpp", "host/sbvh_builder.hpp", "host/Camera.hpp", "host/Constants.hpp", "../include/gmupt.h"]
 
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",

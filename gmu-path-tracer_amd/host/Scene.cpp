@@ -1,0 +1,109 @@
+#include "Scene.hpp"
+#include "CsvParser.hpp"
+#include <fstream>
+#include <stdexcept>
+#include <thread>
+
+namespace {
+void check(int rc) { if (rc != GMUPT_OK) throw std::runtime_error(gmupt_last_error()); }
+}
+
+SceneParams::Entry SceneParams::load(const std::string& paramsPath)
+{
+	Entry e;
+	std::ifstream file(paramsPath);
+	if (file.is_open())
+	{
+		CSVRow row;
+		if (!row.readNextRow(file) || row.size() < 5) throw std::runtime_error("Malformed params file " + paramsPath);
+		for (size_t i = 0; i < 3; i++) e.camera.position[i] = std::stof(row[i]);
+		e.camera.pitch = std::stof(row[3]);
+		e.camera.yaw = std::stof(row[4]);
+		while (row.readNextRow(file))
+		{
+			if (row.size() < 8) throw std::runtime_error("Malformed light row in " + paramsPath);
+			Light light;
+			for (size_t i = 0; i < sizeof(Light) / 4; i++) reinterpret_cast<float*>(&light)[i] = std::stof(row[i]);
+			e.lights.push_back(light);
+		}
+	}
+	else
+	{
+		// default params (Source/Scene.cpp:59-61)
+		e.camera = { {1.0f, 3.0f, 8.0f}, 0.f, 270.f };
+		e.lights.push_back(Light{ {13.0f, 4.5f, 4.5f}, 100.0f, {80.0f, 80.0f, 40.0f}, 0.5f });
+		e.lights.push_back(Light{ {0.0f, 4.5f, 2.0f}, 100.0f, {80.0f, 80.0f, 40.0f}, 0.5f });
+	}
+	return e;
+}
+
+Scene::Scene(gmupt_device* device, const std::string& path)
+	: mDevice(device)
+	, mSceneName(path)
+{
+	loadScene(path);
+
+	std::thread worker(&Scene::createBVH, this); // as Source/Scene.cpp:89: BVH build + upload on a worker thread
+	createPropertyBuffer(mScene.materials);
+
+	std::string paramsPath = path;
+	const auto dot = paramsPath.find_last_of('.');
+	paramsPath = (dot == std::string::npos ? paramsPath : paramsPath.substr(0, dot)) + ".params";
+	const auto params = SceneParams::load(paramsPath);
+	createLights(params.lights);
+
+	mCamera.setPosition(params.camera.position[0], params.camera.position[1], params.camera.position[2]);
+	mCamera.setRotation(params.camera.pitch, params.camera.yaw);
+
+	worker.join();
+}
+
+void Scene::update(float dt)
+{
+	mCamera.update(dt);
+}
+
+void Scene::loadScene(const std::string& path)
+{
+	mScene = (path == "cornell") ? MeshData::cornell() : MeshData::load(path);
+	if (mScene.materials.size() > MAX_LIGHTS) throw std::runtime_error("More than 128 materials (logic.hlsl:8)");
+}
+
+void Scene::createBVH()
+{
+	BVHWrapper bvh(mScene);
+	gmupt_buffer* b = nullptr;
+	check(gmupt_buffer_create(mDevice, GMUPT_BUFFER_BVH_NODES, bvh.mGPUTree.data(), bvh.mGPUTree.size() * sizeof(BVHWrapper::BVHNode), &b)); mBVHBuffer.reset(b);
+	check(gmupt_buffer_create(mDevice, GMUPT_BUFFER_TRIANGLES, bvh.mIndices.data(), bvh.mIndices.size() * sizeof(BVHWrapper::Triangle), &b)); mIndexBuffer.reset(b);
+	check(gmupt_buffer_create(mDevice, GMUPT_BUFFER_VERTICES, bvh.mVertices.data(), bvh.mVertices.size() * sizeof(float), &b)); mVertexBuffer.reset(b);
+	check(gmupt_buffer_create(mDevice, GMUPT_BUFFER_TRI_PROPS, bvh.mTriangleProperties.data(), bvh.mTriangleProperties.size() * sizeof(BVHWrapper::TriangleProperties), &b)); mTriangleProperties.reset(b);
+}
+
+void Scene::createPropertyBuffer(const std::vector<MaterialProperty>& data)
+{
+	gmupt_buffer* b = nullptr;
+	check(gmupt_buffer_create(mDevice, GMUPT_BUFFER_MATERIALS, data.data(), data.size() * sizeof(MaterialProperty), &b));
+	mMaterialPropertyBuffer.reset(b);
+}
+
+void Scene::createLights(const std::vector<Light>& lights)
+{
+	if (lights.size() > MAX_LIGHTS) throw std::runtime_error("More than 128 lights");
+	mLights = {};
+	for (size_t i = 0; i < lights.size(); ++i) mLights[i] = lights[i];
+	mLightCount = lights.size();
+	gmupt_buffer* b = nullptr;
+	check(gmupt_buffer_create(mDevice, GMUPT_BUFFER_LIGHTS, mLights.data(), mLights.size() * sizeof(Light), &b));
+	mLightBuffer.reset(b);
+}
+
+void Scene::setLights(const std::vector<Light>& lights)
+{
+	if (lights.size() > MAX_LIGHTS) throw std::runtime_error("More than 128 lights");
+	mLights = {};
+	for (size_t i = 0; i < lights.size(); ++i) mLights[i] = lights[i];
+	mLightCount = lights.size();
+	check(gmupt_buffer_update(mLightBuffer.get(), mLights.data(), mLights.size() * sizeof(Light)));
+	mCamera.getBuffer()->lightCount = static_cast<uint32_t>(lights.size());
+	mCamera.getBuffer()->iterationCounter = -1; // GUI.cpp: light edits reset the accumulation
+}

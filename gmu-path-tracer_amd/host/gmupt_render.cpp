@@ -1,0 +1,59 @@
+// Headless driver of the C++ host classes: the reference's Window::loop (Source/Window.cpp:60-90: update(dt); draw();)
+// without a window.  Used by tests/test_host_cpp_gpu.py.
+//   gmupt_render --scene cornell|file.gmesh --size WxH --frames N --pool P --live L [--capture] [--dump out.f32] [--build-only]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <exception>
+#include <stdexcept>
+#include <string>
+#include "Renderer.hpp"
+
+int main(int argc, char** argv)
+{
+	std::string scene = "cornell", dump;
+	unsigned w = WIDTH, h = HEIGHT, frames = 16, pool = PATHCOUNT, live = REFERENCE_LIVE_PATHS;
+	bool capture = false, buildOnly = false;
+	for (int i = 1; i < argc; i++) {
+		const std::string a = argv[i];
+		auto next = [&]() -> const char* { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
+		if (a == "--scene") scene = next();
+		else if (a == "--size") { if (std::sscanf(next(), "%ux%u", &w, &h) != 2) return 2; }
+		else if (a == "--frames") frames = std::strtoul(next(), nullptr, 10);
+		else if (a == "--pool") pool = std::strtoul(next(), nullptr, 10);
+		else if (a == "--live") live = std::strtoul(next(), nullptr, 10);
+		else if (a == "--dump") dump = next();
+		else if (a == "--capture") capture = true;
+		else if (a == "--build-only") buildOnly = true;
+		else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
+	}
+	try
+	{
+		if (buildOnly) { // host-only leg (BASELINE config 1): scene load + SBVH build + flatten, no GPU
+			const MeshData mesh = (scene == "cornell") ? MeshData::cornell() : MeshData::load(scene);
+			const auto t0 = std::chrono::steady_clock::now();
+			BVHWrapper bvh(mesh);
+			const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+			std::printf("{\"triangles\": %zu, \"nodes\": %zu, \"references\": %zu, \"sah\": %.6f, \"build_s\": %.4f}\n",
+			            mesh.numTriangles(), bvh.tree().size(), bvh.indices().size(), bvh.sah(), s);
+			return 0;
+		}
+		Renderer renderer(nullptr, { w, h }, scene, 0, pool, live);
+		for (unsigned f = 0; f < frames; f++) { renderer.update(0.f); renderer.draw(); }
+		if (capture) { renderer.requestCapture(); renderer.update(0.f); std::printf("capture %s\n", renderer.lastCapturePath().c_str()); }
+		if (!dump.empty()) {
+			const auto fb = renderer.readFramebuffer();
+			FILE* f = std::fopen(dump.c_str(), "wb");
+			if (!f || std::fwrite(fb.data(), 4, fb.size(), f) != fb.size()) throw std::runtime_error("cannot write " + dump);
+			std::fclose(f);
+		}
+		std::printf("rendered %llu iterations of %ux%u\n", renderer.iterations(), w, h);
+	}
+	catch (const std::exception& e) // main.cpp:19-23
+	{
+		std::fprintf(stderr, "error: %s\n", e.what());
+		return -1;
+	}
+	return 0;
+}

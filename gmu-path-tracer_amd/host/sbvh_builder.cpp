@@ -41,7 +41,7 @@ static inline float clampf(float v, float lo, float hi) { return v < lo ? lo : v
 
 SbvhBuilder::SbvhBuilder(const float* vertices, uint32_t numVertices, const int32_t* indices, uint32_t numTriangles,
                          const gmupt_sbvh_params& params)
-    : mVerts(vertices), mIdx(indices), mNumVerts(numVertices), mNumTris(numTriangles), mP(params)
+    : mVerts(vertices), mIdx(indices), mNumTris(numTriangles), mP(params)
 {
     for (uint32_t i = 0; i < numTriangles * 3u; i++)
         if (indices[i] < 0 || (uint32_t)indices[i] >= numVertices) throw std::invalid_argument("sbvh: vertex index out of range");

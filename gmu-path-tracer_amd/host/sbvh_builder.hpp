@@ -67,7 +67,7 @@ private:
 
     const float* mVerts;
     const int32_t* mIdx;
-    uint32_t mNumVerts, mNumTris;
+    uint32_t mNumTris;
     gmupt_sbvh_params mP;
 
     std::vector<Ref> mStack;

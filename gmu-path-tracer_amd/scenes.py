@@ -190,3 +190,26 @@ def build_scene(mesh, sbvh_params=None):
              "sah": built["sah"], "depth": built["depth"], "ref_triangle": built["ref_triangle"],
              "num_triangles": int(mesh["indices"].shape[0])}
     return scene
+
+
+def save_gmesh(mesh, path, params_path=None):
+    """Writes the ".gmesh" dump host/MeshData.cpp reads, and optionally the sibling ".params" CSV in the reference's format
+    (row 0: camera x,y,z,pitch,yaw; rows 1..: light x,y,z,falloff,r,g,b,radius -- Source/Scene.cpp:34-55)."""
+    nv, nt, nm = mesh["verts"].shape[0], mesh["indices"].shape[0], mesh["materials"].shape[0]
+    with open(path, "wb") as f:
+        f.write(b"GMESH001")
+        f.write(np.array([nv, nt, nm, 1 if "uv" in mesh else 0], np.uint32).tobytes())
+        f.write(np.ascontiguousarray(mesh["verts"], np.float32).tobytes())
+        f.write(np.ascontiguousarray(mesh["normals"], np.float32).tobytes())
+        if "uv" in mesh:
+            f.write(np.ascontiguousarray(mesh["uv"], np.float32).tobytes())
+        f.write(np.ascontiguousarray(mesh["vertex_material"], np.uint32).tobytes())
+        f.write(np.ascontiguousarray(mesh["indices"], np.int32).tobytes())
+        f.write(np.ascontiguousarray(mesh["materials"]).tobytes())
+    if params_path:
+        with open(params_path, "w") as f:
+            f.write(", ".join(repr(float(v)) for v in mesh["camera"]) + "\n")
+            for i in range(mesh["light_count"]):
+                L = mesh["lights"][i]
+                row = list(L["position"]) + [L["falloff"]] + list(L["emission"]) + [L["radius"]]
+                f.write(", ".join(repr(float(v)) for v in row) + "\n")

@@ -1,0 +1,63 @@
+"""Tests of the C++ host classes (Renderer / Scene / BVHWrapper / Camera mirror of the reference API) through the headless
+driver gmu-path-tracer_amd/host/gmupt_render."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "gmu-path-tracer_amd", "host")
+EXE = os.path.join(HOST, "gmupt_render")
+
+
+@pytest.fixture(scope="module")
+def exe(pkg):
+    pkg.capi.lib()
+    subprocess.run(["make", "-C", HOST, "-s"], check=True)
+    return EXE
+
+
+def test_build_only_matches_python_builder(exe, pkg, cornell_scene, tmp_path):
+    out = json.loads(subprocess.run([exe, "--build-only", "--scene", "cornell"], check=True, capture_output=True, text=True).stdout)
+    assert out["triangles"] == 34 and out["nodes"] == cornell_scene["nodes"].shape[0] and out["references"] == 34
+    assert abs(out["sah"] - cornell_scene["sah"]) < 1e-4
+    mesh = pkg.scenes.random_triangles_mesh(1500, seed=9)
+    path = str(tmp_path / "soup.gmesh")
+    pkg.scenes.save_gmesh(mesh, path, str(tmp_path / "soup.params"))
+    out = json.loads(subprocess.run([exe, "--build-only", "--scene", path], check=True, capture_output=True, text=True).stdout)
+    ref = pkg.scenes.build_scene(mesh)
+    assert out["nodes"] == ref["nodes"].shape[0] and out["references"] == ref["tris"].shape[0] and abs(out["sah"] - ref["sah"]) < 1e-3
+
+
+def test_missing_scene_is_a_runtime_error(exe):
+    r = subprocess.run([exe, "--build-only", "--scene", "/nonexistent/x.gmesh"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Non existing scene" in r.stderr            # wording of Source/Scene.cpp:79, exit path of main.cpp:19-23
+
+
+@pytest.mark.gpu
+def test_cpp_renderer_equals_capi_render(exe, pkg, device, tmp_path):
+    # Renderer::update()/draw() frames through the C++ classes == the same frames driven through the C-ABI from Python
+    mesh = pkg.scenes.spheres_mesh(n_spheres=12, subdiv=2, seed=7, floor_quads=4)
+    path = str(tmp_path / "s12.gmesh")
+    pkg.scenes.save_gmesh(mesh, path, str(tmp_path / "s12.params"))
+    W, H, P, frames = 48, 27, 4096, 20
+    dump = str(tmp_path / "fb.f32")
+    subprocess.run([exe, "--scene", path, "--size", "%dx%d" % (W, H), "--frames", str(frames), "--pool", str(P), "--live", str(P),
+                    "--dump", dump, "--capture"], check=True, cwd=str(tmp_path))
+    fb_cpp = np.fromfile(dump, dtype=np.float32).reshape(H, W, 4)
+    scene = pkg.scenes.build_scene(mesh)
+    sb = pkg.capi.SceneBuffers(device, scene)
+    r = pkg.capi.Renderer(device, W, H, pool_paths=P)
+    r.bind_scene(sb)
+    cam = pkg.capi.Camera(W, H); cam.set_pose(*scene["camera"])
+    for _ in range(frames):
+        cam.update(0.0); r.set_camera(cam.buffer); r.iterate()
+    assert np.array_equal(fb_cpp.view(np.uint32), r.framebuffer().view(np.uint32))
+    png = tmp_path / "Captures" / "potato0.png"                               # Renderer.cpp:404 naming
+    assert png.exists() and png.read_bytes()[:8] == b"\x89PNG\r\n\x1a\n"
+    from PIL import Image
+    img = np.asarray(Image.open(str(png)))
+    assert img.shape == (H, W, 4) and np.array_equal(img[..., :3], (fb_cpp[..., :3] * 255).astype(np.uint8)) and np.all(img[..., 3] == 255)
+    r.close(); sb.close()
