@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -31,8 +32,8 @@ void launch_clear(const RenderParams& p, hipStream_t s);
 void launch_logic(const RenderParams& p, hipStream_t s);
 void launch_scan(const RenderParams& p, int clearFrame, hipStream_t s);
 void launch_material(const RenderParams& p, int clearFrame, hipStream_t s);
-void launch_extend(const RenderParams& p, uint32_t blocks, bool stats, hipStream_t s);
-void launch_shadow(const RenderParams& p, uint32_t blocks, bool stats, hipStream_t s);
+void launch_extend(const RenderParams& p, uint32_t blocks, bool stats, bool refLayout, hipStream_t s);
+void launch_shadow(const RenderParams& p, uint32_t blocks, bool stats, bool refLayout, hipStream_t s);
 void launch_detmath(int fn, const float* x, const float* y, float* out, uint32_t n, hipStream_t s);
 uint32_t traversal_block_threads();
 uint32_t traversal_overflow_entries();
@@ -159,6 +160,9 @@ struct gmupt_renderer {
     std::vector<StageEvents> evPool; size_t evUsed = 0;
     double msStage[5] = { 0, 0, 0, 0, 0 }; uint64_t timedIters = 0;
     std::vector<void*> allocs;
+    // packed traversal copy of the bound scene
+    void* travNodes = nullptr; void* travTris = nullptr;
+    bool refTraversal = false; // GMUPT_TRAVERSAL=ref: ray casts straight on the reference-layout buffers (A/B timing)
 };
 
 static int dev_alloc(gmupt_renderer* r, void** ptr, size_t bytes, int fill)
@@ -191,6 +195,8 @@ extern "C" void gmupt_renderer_destroy(gmupt_renderer* r)
     for (void* a : r->allocs) (void)hipFree(a);
     if (r->p.fb) (void)hipFree(r->p.fb);
     if (r->p.listHead) (void)hipFree(r->p.listHead);
+    if (r->travNodes) (void)hipFree(r->travNodes);
+    if (r->travTris) (void)hipFree(r->travTris);
     if (r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
 }
@@ -203,6 +209,7 @@ extern "C" int gmupt_renderer_create(gmupt_device* dev, const gmupt_renderer_des
     gmupt_renderer* r = new (std::nothrow) gmupt_renderer();
     if (!r) return fail(GMUPT_ERR_OUT_OF_MEMORY, "gmupt_renderer_create: out of host memory");
     r->dev = dev; r->desc = *desc;
+    { const char* tv = std::getenv("GMUPT_TRAVERSAL"); r->refTraversal = tv && std::strcmp(tv, "ref") == 0; }
     if (r->desc.pool_paths == 0) r->desc.pool_paths = GMUPT_PATHCOUNT;
     if (r->desc.live_paths == 0 || r->desc.live_paths > r->desc.pool_paths) r->desc.live_paths = r->desc.pool_paths;
     const uint32_t P = r->desc.pool_paths, L = r->desc.live_paths;
@@ -245,6 +252,80 @@ extern "C" int gmupt_renderer_create(gmupt_device* dev, const gmupt_renderer_des
     return GMUPT_OK;
 }
 
+// Packs the reference-layout BVH into the traversal records of pt_device.hpp (Node64 / Tri48).  Host-side, once per bind.
+static int build_traversal_copy(gmupt_renderer* r, const gmupt_buffer* nodesB, const gmupt_buffer* trisB, const gmupt_buffer* vertsB)
+{
+    HIP_TRY(hipSetDevice(r->dev->id));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    const size_t N = nodesB->elems, R = trisB->elems, V = vertsB->elems;
+    std::vector<gmupt_bvh_node> nodes(N);
+    std::vector<gmupt_triangle> tris(R ? R : 1);
+    std::vector<float> verts(V ? V * 3 : 3);
+    HIP_TRY(hipMemcpy(nodes.data(), nodesB->dptr, N * sizeof(gmupt_bvh_node), hipMemcpyDeviceToHost));
+    if (R) HIP_TRY(hipMemcpy(tris.data(), trisB->dptr, R * sizeof(gmupt_triangle), hipMemcpyDeviceToHost));
+    if (V) HIP_TRY(hipMemcpy(verts.data(), vertsB->dptr, V * 12, hipMemcpyDeviceToHost));
+
+    // validate what the kernels will index with (a malformed tree must not become an out-of-bounds access on the GPU)
+    std::vector<int32_t> innerIndex(N, -1);
+    int32_t numInner = 0;
+    for (size_t i = 0; i < N; i++) {
+        const gmupt_bvh_node& n = nodes[i];
+        if (n.isLeaf) {
+            if (n.left < 0 || n.right < n.left || (size_t)n.right > R) return fail(GMUPT_ERR_INVALID_ARGUMENT, "bind_scene: leaf %zu has triangle range [%d, %d) outside [0, %zu)", i, n.left, n.right, R);
+        } else {
+            if (n.left <= (int32_t)i || n.right <= (int32_t)i || (size_t)n.left >= N || (size_t)n.right >= N) return fail(GMUPT_ERR_INVALID_ARGUMENT, "bind_scene: inner node %zu has children (%d, %d) outside (%zu, %zu)", i, n.left, n.right, i, N);
+            innerIndex[i] = numInner++;
+        }
+    }
+    for (size_t i = 0; i < R; i++)
+        for (int k = 0; k < 3; k++)
+            if (tris[i].v[k] < 0 || (size_t)tris[i].v[k] >= V) return fail(GMUPT_ERR_INVALID_ARGUMENT, "bind_scene: triangle record %zu references vertex %d of %zu", i, tris[i].v[k], V);
+
+    auto desc = [&](int32_t child) -> int32_t {
+        const gmupt_bvh_node& c = nodes[(size_t)child];
+        if (!c.isLeaf) return innerIndex[(size_t)child];
+        // an empty leaf cannot be expressed by "first record + last flag": point it at a degenerate sentinel record
+        return ~(c.right > c.left ? c.left : (int32_t)R);
+    };
+    std::vector<Node64> packed((size_t)numInner ? (size_t)numInner : 1);
+    std::memset(packed.data(), 0, packed.size() * sizeof(Node64));
+    for (size_t i = 0; i < N; i++) {
+        if (nodes[i].isLeaf) continue;
+        const gmupt_bvh_node& L = nodes[(size_t)nodes[i].left];
+        const gmupt_bvh_node& Rn = nodes[(size_t)nodes[i].right];
+        Node64& o = packed[(size_t)innerIndex[i]];
+        o.a[0] = L.min[0]; o.a[1] = L.min[1]; o.a[2] = L.min[2]; o.a[3] = L.max[0];
+        o.b[0] = L.max[1]; o.b[1] = L.max[2]; o.b[2] = Rn.min[0]; o.b[3] = Rn.min[1];
+        o.c[0] = Rn.min[2]; o.c[1] = Rn.max[0]; o.c[2] = Rn.max[1]; o.c[3] = Rn.max[2];
+        o.d[0] = desc(nodes[i].left); o.d[1] = desc(nodes[i].right); o.d[2] = 0; o.d[3] = 0;
+    }
+    std::vector<Tri48> ptris(R + 1);
+    std::memset(ptris.data(), 0, ptris.size() * sizeof(Tri48));
+    for (size_t i = 0; i < R; i++) {
+        const float* v0 = &verts[3 * (size_t)tris[i].v[0]]; const float* v1 = &verts[3 * (size_t)tris[i].v[1]]; const float* v2 = &verts[3 * (size_t)tris[i].v[2]];
+        Tri48& t = ptris[i];
+        t.r0[0] = v0[0]; t.r0[1] = v0[1]; t.r0[2] = v0[2];
+        t.r0[3] = v1[0] - v0[0]; t.r1[0] = v1[1] - v0[1]; t.r1[1] = v1[2] - v0[2];   // e1 = v1 - v0 (extensionRayCast.hlsl:40)
+        t.r1[2] = v2[0] - v0[0]; t.r1[3] = v2[1] - v0[1]; t.r2[0] = v2[2] - v0[2];   // e2 = v2 - v0 (:41)
+    }
+    const uint32_t one = 1u;
+    for (size_t i = 0; i < N; i++)
+        if (nodes[i].isLeaf && nodes[i].right > nodes[i].left) std::memcpy(&ptris[(size_t)nodes[i].right - 1].r2[1], &one, 4);
+    std::memcpy(&ptris[R].r2[1], &one, 4); // sentinel: all-zero triangle (det = 0, rejected), last flag set
+
+    if (r->travNodes) { HIP_TRY(hipFree(r->travNodes)); r->travNodes = nullptr; }
+    if (r->travTris) { HIP_TRY(hipFree(r->travTris)); r->travTris = nullptr; }
+    HIP_TRY(hipMalloc(&r->travNodes, packed.size() * sizeof(Node64)));
+    HIP_TRY(hipMalloc(&r->travTris, ptris.size() * sizeof(Tri48)));
+    HIP_TRY(hipMemcpy(r->travNodes, packed.data(), packed.size() * sizeof(Node64), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(r->travTris, ptris.data(), ptris.size() * sizeof(Tri48), hipMemcpyHostToDevice));
+    TravScene& t = r->p.trav;
+    t.nodes = (const Node64*)r->travNodes; t.tris = (const Tri48*)r->travTris;
+    t.rootDesc = nodes[0].isLeaf ? ~(nodes[0].right > nodes[0].left ? nodes[0].left : (int32_t)R) : innerIndex[0];
+    for (int k = 0; k < 3; k++) { t.rootMin[k] = nodes[0].min[k]; t.rootMax[k] = nodes[0].max[k]; }
+    return GMUPT_OK;
+}
+
 extern "C" int gmupt_renderer_bind_scene(gmupt_renderer* r, const gmupt_buffer* nodes, const gmupt_buffer* triangles, const gmupt_buffer* vertices,
                                          const gmupt_buffer* lights, const gmupt_buffer* tri_props, const gmupt_buffer* materials)
 {
@@ -258,6 +339,8 @@ extern "C" int gmupt_renderer_bind_scene(gmupt_renderer* r, const gmupt_buffer* 
     s.nodes = (const DNode*)nodes->dptr; s.tris = (const gmupt_triangle*)triangles->dptr; s.verts = (const float*)vertices->dptr;
     s.lights = (const gmupt_light*)lights->dptr; s.props = (const gmupt_tri_props*)tri_props->dptr; s.materials = (const gmupt_material*)materials->dptr;
     s.numNodes = (uint32_t)nodes->elems; s.numTris = (uint32_t)triangles->elems; s.numVerts = (uint32_t)vertices->elems; s.numMaterials = (uint32_t)materials->elems;
+    int rc = build_traversal_copy(r, nodes, triangles, vertices);
+    if (rc != GMUPT_OK) return rc;
     r->sceneBound = true;
     return GMUPT_OK;
 }
@@ -311,8 +394,8 @@ static int run_iteration(gmupt_renderer* r, bool doShade, bool doExtend, bool do
         launch_material(p, clearFrame, r->stream);
         if (ev) HIP_TRY(hipEventRecord(ev->e[3], r->stream));
     }
-    if (doExtend) { launch_extend(p, r->travBlocks, stats, r->stream); if (ev) HIP_TRY(hipEventRecord(ev->e[4], r->stream)); }
-    if (doShadow) { launch_shadow(p, r->travBlocks, stats, r->stream); if (ev) HIP_TRY(hipEventRecord(ev->e[5], r->stream)); }
+    if (doExtend) { launch_extend(p, r->travBlocks, stats, r->refTraversal, r->stream); if (ev) HIP_TRY(hipEventRecord(ev->e[4], r->stream)); }
+    if (doShadow) { launch_shadow(p, r->travBlocks, stats, r->refTraversal, r->stream); if (ev) HIP_TRY(hipEventRecord(ev->e[5], r->stream)); }
     HIP_TRY(hipGetLastError());
     return GMUPT_OK;
 }

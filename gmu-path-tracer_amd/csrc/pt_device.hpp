@@ -63,6 +63,24 @@ struct SceneView {
     uint32_t numNodes, numTris, numVerts, numMaterials;
 };
 
+// Packed traversal copy of the scene, built at bind time (gmupt_renderer_bind_scene) from the reference-layout buffers.
+// Node64: both children of one inner node -- boxes (12 floats) + child descriptors; inner nodes only, in the flatten order.
+//   float4 a = (lmin.xyz, lmax.x)  b = (lmax.yz, rmin.xy)  c = (rmin.z, rmax.xyz)  int4 d = (leftDesc, rightDesc, 0, 0)
+//   descriptor >= 0: index of an inner Node64; < 0: leaf whose first triangle record is ~descriptor
+// Tri48: one SBVH reference -- v0, e1 = v1 - v0, e2 = v2 - v0 (the subtractions the shader does per test, done once in
+//   binary32 on the host: bit-identical), then a flag word: != 0 on the last record of a leaf.
+//   float4 r0 = (v0.xyz, e1.x)  r1 = (e1.yz, e2.xy)  r2 = (e2.z, lastFlag, 0, 0)
+struct alignas(64) Node64 { float a[4], b[4], c[4]; int32_t d[4]; };
+struct alignas(16) Tri48 { float r0[4], r1[4], r2[4]; };
+static_assert(sizeof(Node64) == 64 && sizeof(Tri48) == 48, "packed traversal records");
+
+struct TravScene {
+    const Node64* nodes;
+    const Tri48* tris;
+    int32_t rootDesc;
+    float rootMin[3], rootMax[3];
+};
+
 struct RenderParams {
     float* state;          // F_COUNT * P words
     uint32_t P, L;         // pool / live slots
@@ -84,6 +102,7 @@ struct RenderParams {
     uint32_t ovfStride;    // threads of the traversal grid
     gmupt_camera_buffer cam;
     SceneView scene;
+    TravScene trav;
 };
 
 } // namespace gmupt

@@ -1,0 +1,497 @@
+// Ray-cast kernels for gfx950: extension (closest hit + light spheres) and shadow (any hit).
+//
+//   k_extend / k_shadow          packed traversal data (default): 64-byte two-child nodes, 48-byte pre-gathered triangles,
+//                                while-while loop structure, per-lane LDS stacks.
+//   k_extend_ref / k_shadow_ref  the same algorithm straight on the reference's buffers (48-B nodes, 16-B triangle records,
+//                                12-B vertices).  Kept for A/B timing in one process (GMUPT_TRAVERSAL=ref) and as the
+//                                executable statement of what the packed kernels must reproduce bit for bit.
+//
+// What must not change (it decides results): the slab test arithmetic and its "hit iff result > 0" rule with no pruning
+// against the current closest hit (extensionRayCast.hlsl:79-94,132-159), the near-child-first visit order (closest-hit ties
+// are resolved by visit order, `t < distance` strict, :64-74), the Moeller-Trumbore operation order (:38-77), and the
+// shadow acceptance rule t in (1e-8, 1e8), |d t| < lightDistance (shadowRayCast.hlsl:16-47,88-91).
+// What is free: memory layout, loop structure, and -- for the any-hit shadow ray only -- the visit order.
+#include "pt_device.hpp"
+#include "detmath.hpp"
+#include "pt_kernel_util.hpp"
+
+namespace gmupt {
+
+// rayAABBIntersection: extensionRayCast.hlsl:79-94 == shadowRayCast.hlsl:49-63
+__device__ __forceinline__ float ray_aabb(float4 mn, float4 mx, f3 o, f3 invdir)
+{
+    const float fx = (mx.x - o.x) * invdir.x, fy = (mx.y - o.y) * invdir.y, fz = (mx.z - o.z) * invdir.z;
+    const float nx = (mn.x - o.x) * invdir.x, ny = (mn.y - o.y) * invdir.y, nz = (mn.z - o.z) * invdir.z;
+    const float tmaxx = hmax(fx, nx), tmaxy = hmax(fy, ny), tmaxz = hmax(fz, nz);
+    const float tminx = hmin(fx, nx), tminy = hmin(fy, ny), tminz = hmin(fz, nz);
+    const float t1 = hmin(tmaxx, hmin(tmaxy, tmaxz));
+    const float t0 = hmax(tminx, hmax(tminy, tminz));
+    return (t1 >= t0) ? (t0 > 0.0f ? t0 : t1) : -1.0f;
+}
+
+constexpr int kTravBlock = 256;
+constexpr int kLdsStack = 24;   // entries per lane kept in LDS; deeper entries spill to a global overflow array
+constexpr int kMaxStack = 64;   // SBVH depth limit (Include/Nvidia-SBVH/SplitBVHBuilder.h:38)
+
+struct TravStack {
+    int* lds;       // s_stack + threadIdx.x, stride kTravBlock
+    int* ovf;       // global overflow + global thread id, stride ovfStride
+    uint32_t ovfStride;
+    uint32_t ptr;
+    __device__ __forceinline__ void push(int v, DevStats* st)
+    {
+        if (ptr < kLdsStack) lds[ptr * kTravBlock] = v;
+        else if (ptr < kMaxStack) ovf[(size_t)(ptr - kLdsStack) * ovfStride] = v;
+        else st->stackOverflow = 1u;
+        ptr++;
+    }
+    __device__ __forceinline__ int pop()
+    {
+        if (ptr == 0) return -1;   // the reference's sentinel stack[0] = -1 (extensionRayCast.hlsl:100)
+        --ptr;
+        if (ptr < kLdsStack) return lds[ptr * kTravBlock];
+        if (ptr < kMaxStack) return ovf[(size_t)(ptr - kLdsStack) * ovfStride];
+        return -1;
+    }
+};
+
+struct TravCount { uint32_t inner, leaves, tris; };
+
+struct ExtHit { f3 hitPoint, bary; int4 tri; };
+
+__device__ __forceinline__ f3 load_vertex(const float* verts, int idx) { const float* v = verts + 3 * (size_t)idx; return mk3(v[0], v[1], v[2]); }
+
+// extensionRayCast.hlsl:96-166 + rayTriangleIntersection :38-77
+template <bool STATS>
+__device__ __forceinline__ float bvh_closest(const SceneView& sc, f3 o, f3 d, ExtHit& hit, TravStack& stk, DevStats* dst, TravCount& tc)
+{
+    float distance = kFltMax;
+    const f3 invdir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    stk.ptr = 0;
+    const DNode root = sc.nodes[0];
+    if (!(ray_aabb(root.mn, root.mx, o, invdir) > 0.0f)) return distance;
+    int4 link = root.link;
+    for (;;) {
+        if (link.z) { // leaf
+            if (STATS) tc.leaves++;
+            for (int i = link.x; i < link.y; i++) {
+                const int4 T = *reinterpret_cast<const int4*>(&sc.tris[i]);
+                const f3 v0 = load_vertex(sc.verts, T.x), v1 = load_vertex(sc.verts, T.y), v2 = load_vertex(sc.verts, T.z);
+                if (STATS) tc.tris++;
+                const f3 e1 = v1 - v0, e2 = v2 - v0;
+                const f3 pvec = cross3(d, e2);
+                const float det = dot3(e1, pvec);
+                if (det > -kEpsilon && det < kEpsilon) continue;
+                const float invDet = 1.0f / det;
+                const f3 tvec = o - v0;
+                const float u = dot3(tvec, pvec) * invDet;
+                if (u < 0.0f || u > 1.0f) continue;
+                const f3 qvec = cross3(tvec, e1);
+                const float v = dot3(d, qvec) * invDet;
+                if (v < 0.0f || u + v > 1.0f) continue;
+                const float t = dot3(e2, qvec) * invDet;
+                if (t >= 0.0f && t < distance) {
+                    distance = t;
+                    hit.hitPoint = o + d * t;
+                    hit.bary = mk3(1.0f - u - v, u, v);
+                    hit.tri = T;
+                }
+            }
+        } else {
+            if (STATS) tc.inner++;
+            const DNode left = sc.nodes[link.x];
+            const DNode right = sc.nodes[link.y];
+            const float leftHit = ray_aabb(left.mn, left.mx, o, invdir);
+            const float rightHit = ray_aabb(right.mn, right.mx, o, invdir);
+            if (leftHit > 0.0f && rightHit > 0.0f) {
+                if (leftHit > rightHit) { stk.push(link.x, dst); link = right.link; }
+                else { stk.push(link.y, dst); link = left.link; }
+                continue;
+            } else if (leftHit > 0.0f) { link = left.link; continue; }
+            else if (rightHit > 0.0f) { link = right.link; continue; }
+        }
+        const int idx = stk.pop();
+        if (idx < 0) break;
+        link = sc.nodes[idx].link;
+    }
+    return distance;
+}
+
+// shadowRayCast.hlsl:65-136 + rayTriangleIntersection :16-47
+template <bool STATS>
+__device__ __forceinline__ bool bvh_any(const SceneView& sc, f3 o, f3 d, float lightDistance, TravStack& stk, DevStats* dst, TravCount& tc)
+{
+    const f3 invdir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    stk.ptr = 0;
+    const DNode root = sc.nodes[0];
+    if (!(ray_aabb(root.mn, root.mx, o, invdir) > 0.0f)) return false;
+    int4 link = root.link;
+    for (;;) {
+        if (link.z) {
+            if (STATS) tc.leaves++;
+            for (int i = link.x; i < link.y; i++) {
+                const int4 T = *reinterpret_cast<const int4*>(&sc.tris[i]);
+                const f3 v0 = load_vertex(sc.verts, T.x), v1 = load_vertex(sc.verts, T.y), v2 = load_vertex(sc.verts, T.z);
+                if (STATS) tc.tris++;
+                const f3 e1 = v1 - v0, e2 = v2 - v0;
+                const f3 pvec = cross3(d, e2);
+                const float det = dot3(e1, pvec);
+                if (det > -kEpsilon && det < kEpsilon) continue;
+                const float invDet = 1.0f / det;
+                const f3 tvec = o - v0;
+                const float u = dot3(tvec, pvec) * invDet;
+                if (u < 0.0f || u > 1.0f) continue;
+                const f3 qvec = cross3(tvec, e1);
+                const float v = dot3(d, qvec) * invDet;
+                if (v < 0.0f || u + v > 1.0f) continue;
+                const float t = dot3(e2, qvec) * invDet;
+                if (t > kEpsilon && t < 1.0f / kEpsilon) {
+                    const float dist = length3(d * t);
+                    if (dist < lightDistance) return true;
+                }
+            }
+        } else {
+            if (STATS) tc.inner++;
+            const DNode left = sc.nodes[link.x];
+            const DNode right = sc.nodes[link.y];
+            const float leftHit = ray_aabb(left.mn, left.mx, o, invdir);
+            const float rightHit = ray_aabb(right.mn, right.mx, o, invdir);
+            if (leftHit > 0.0f && rightHit > 0.0f) {
+                if (leftHit > rightHit) { stk.push(link.x, dst); link = right.link; }
+                else { stk.push(link.y, dst); link = left.link; }
+                continue;
+            } else if (leftHit > 0.0f) { link = left.link; continue; }
+            else if (rightHit > 0.0f) { link = right.link; continue; }
+        }
+        const int idx = stk.pop();
+        if (idx < 0) break;
+        link = sc.nodes[idx].link;
+    }
+    return false;
+}
+
+__device__ __forceinline__ void flush_counts(DevStats* st, const TravCount& tc, uint32_t rays, bool ext)
+{
+    // wave reduction, one atomic per wave and counter
+    uint32_t a = tc.inner, b = tc.leaves, c = tc.tris, r = rays;
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); c += __shfl_down(c, off); r += __shfl_down(r, off); }
+    if ((threadIdx.x & 63) == 0) {
+        if (ext) { atomicAdd(&st->extInner, (unsigned long long)a); atomicAdd(&st->extLeaves, (unsigned long long)b); atomicAdd(&st->extTris, (unsigned long long)c); atomicAdd(&st->extRays, (unsigned long long)r); }
+        else { atomicAdd(&st->shInner, (unsigned long long)a); atomicAdd(&st->shLeaves, (unsigned long long)b); atomicAdd(&st->shTris, (unsigned long long)c); atomicAdd(&st->shRays, (unsigned long long)r); }
+    }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kTravBlock) void k_extend_ref(RenderParams p)
+{
+    __shared__ int s_stack[kLdsStack * kTravBlock];
+    const uint32_t gtid = blockIdx.x * kTravBlock + threadIdx.x;
+    const uint32_t stride = gridDim.x * kTravBlock;
+    TravStack stk; stk.lds = s_stack + threadIdx.x; stk.ovf = p.ovfStack + gtid; stk.ovfStride = p.ovfStride; stk.ptr = 0;
+    TravCount tc = { 0, 0, 0 }; uint32_t rays = 0;
+    const uint32_t count = p.qc[QC_EXT_COUNT];
+    const uint32_t* qExt = p.queues + (size_t)Q_EXT_RAY * p.P;
+    for (uint32_t q = gtid; q < count; q += stride) {
+        const uint32_t index = qExt[q];                                      // extensionRayCast.hlsl:210
+        if (index == kQueueHole) continue;
+        const f3 o = ld3(p, F_RAY_OX, index), d = ld3(p, F_RAY_DX, index);   // :213-214
+        ExtHit hit; hit.hitPoint = mk3(0, 0, 0); hit.bary = mk3(0, 0, 0); hit.tri = make_int4(0, 0, 0, 0);
+        float distance = bvh_closest<STATS>(p.scene, o, d, hit, stk, p.stats, tc); // :216
+        if (STATS) rays++;
+        if (distance < kFltMax) {                                            // :218-225
+            st3(p, F_SP_X, index, hit.hitPoint);
+            st3(p, F_BARY_X, index, hit.bary);
+            stu(p, F_TRI_0, index, (uint32_t)hit.tri.x); stu(p, F_TRI_1, index, (uint32_t)hit.tri.y);
+            stu(p, F_TRI_2, index, (uint32_t)hit.tri.z); stu(p, F_TRI_MAT, index, (uint32_t)hit.tri.w);
+        }
+        // rayLightIntersection :168-194
+        uint32_t lightIndex = 0;
+        const uint32_t lc = p.cam.lightCount < GMUPT_MAX_LIGHTS ? p.cam.lightCount : GMUPT_MAX_LIGHTS;
+        for (uint32_t li = 0; li < lc; li++) {
+            const gmupt_light L = p.scene.lights[li];
+            const f3 position = mk3(L.position[0], L.position[1], L.position[2]) - o;
+            const float radius2 = L.radius * L.radius;
+            const float tca = dot3(position, d);
+            const float d2 = dot3(position, position) - tca * tca;
+            if (d2 > radius2) continue;
+            const float thc = dsqrt(radius2 - d2);
+            float t0 = tca - thc;
+            const float t1 = tca + thc;
+            if (t0 < 0.0f) t0 = t1;
+            if (t0 > 0.0f && t0 < distance) { distance = t0; lightIndex = li + 1; }
+        }
+        stu(p, F_IS_EMITTER, index, lightIndex);                             // :231
+        stf(p, F_HIT_DIST, index, distance);                                 // :232
+    }
+    if (STATS) flush_counts(p.stats, tc, rays, true);
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kTravBlock) void k_shadow_ref(RenderParams p)
+{
+    __shared__ int s_stack[kLdsStack * kTravBlock];
+    const uint32_t gtid = blockIdx.x * kTravBlock + threadIdx.x;
+    const uint32_t stride = gridDim.x * kTravBlock;
+    const uint32_t count = p.qc[QC_SHADOWRAY];                               // shadowRayCast.hlsl:151
+    __syncthreads();
+    if (gtid == 0) {
+        // :144-148: QC[0..3] = (0, QC1 + QC0, 0, 0).  Nothing else in this kernel reads those words.
+        const uint32_t q0 = p.qc[QC_NEWPATH], q1 = p.qc[QC_LASTPATHCNT];
+        p.qc[QC_NEWPATH] = 0; p.qc[QC_LASTPATHCNT] = q0 + q1; p.qc[QC_MATUE4] = 0; p.qc[QC_MATGLASS] = 0;
+    }
+    TravStack stk; stk.lds = s_stack + threadIdx.x; stk.ovf = p.ovfStack + gtid; stk.ovfStride = p.ovfStride; stk.ptr = 0;
+    TravCount tc = { 0, 0, 0 }; uint32_t rays = 0;
+    const uint32_t* qSh = p.queues + (size_t)Q_SHADOW_RAY * p.P;
+    for (uint32_t q = gtid; q < count; q += stride) {
+        const uint32_t index = qSh[q];                                       // :159
+        const f3 o = ld3(p, F_SH_OX, index), d = ld3(p, F_SH_DX, index);     // :162-163
+        const float lightDistance = ldf(p, F_LIGHT_DIST, index);             // :164
+        const bool inShadow = bvh_any<STATS>(p.scene, o, d, lightDistance, stk, p.stats, tc); // :166
+        if (STATS) rays++;
+        stu(p, F_IN_SHADOW, index, inShadow ? 1u : 0u);                      // :167
+    }
+    if (STATS) flush_counts(p.stats, tc, rays, false);
+}
+
+
+// ------------------------------------------------------------------------------------------------ packed traversal data
+// child descriptor: >= 0 inner node index into nodes64; < 0 leaf starting at triangle record ~desc; INT_MIN = traversal done
+constexpr int kDone = (int)0x80000000;
+
+// slab test on the packed node: same arithmetic as ray_aabb; v_min/v_max differ from hmin/hmax only in the sign of a zero
+// result, which none of the comparisons below can observe
+__device__ __forceinline__ float ray_box(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, f3 o, f3 invdir)
+{
+    const float fx = (mxx - o.x) * invdir.x, fy = (mxy - o.y) * invdir.y, fz = (mxz - o.z) * invdir.z;
+    const float nx = (mnx - o.x) * invdir.x, ny = (mny - o.y) * invdir.y, nz = (mnz - o.z) * invdir.z;
+    const float t1 = __builtin_fminf(__builtin_fmaxf(fx, nx), __builtin_fminf(__builtin_fmaxf(fy, ny), __builtin_fmaxf(fz, nz)));
+    const float t0 = __builtin_fmaxf(__builtin_fminf(fx, nx), __builtin_fmaxf(__builtin_fminf(fy, ny), __builtin_fminf(fz, nz)));
+    return (t1 >= t0) ? (t0 > 0.0f ? t0 : t1) : -1.0f;
+}
+
+struct PackedStack {
+    int* lds; int* ovf; uint32_t ovfStride; uint32_t ptr;
+    __device__ __forceinline__ void push(int v, DevStats* st)
+    {
+        if (ptr < kLdsStack) lds[ptr * kTravBlock] = v;
+        else if (ptr < kMaxStack) ovf[(size_t)(ptr - kLdsStack) * ovfStride] = v;
+        else st->stackOverflow = 1u;
+        ptr++;
+    }
+    __device__ __forceinline__ int pop()
+    {
+        if (ptr == 0) return kDone;
+        --ptr;
+        if (ptr < kLdsStack) return lds[ptr * kTravBlock];
+        if (ptr < kMaxStack) return ovf[(size_t)(ptr - kLdsStack) * ovfStride];
+        return kDone;
+    }
+};
+
+// one inner step: test both children, descend into the nearer hit child, defer the other (extensionRayCast.hlsl:126-159)
+__device__ __forceinline__ int inner_step(const TravScene& ts, int cur, f3 o, f3 invdir, PackedStack& stk, DevStats* dst)
+{
+    const float4* n = reinterpret_cast<const float4*>(ts.nodes + cur);
+    const float4 a = n[0], b = n[1], c = n[2];
+    const int4 d = *reinterpret_cast<const int4*>(n + 3);
+    const float leftHit = ray_box(a.x, a.y, a.z, a.w, b.x, b.y, o, invdir);
+    const float rightHit = ray_box(b.z, b.w, c.x, c.y, c.z, c.w, o, invdir);
+    if (leftHit > 0.0f && rightHit > 0.0f) {
+        if (leftHit > rightHit) { stk.push(d.x, dst); return d.y; }
+        stk.push(d.y, dst); return d.x;
+    }
+    if (leftHit > 0.0f) return d.x;
+    if (rightHit > 0.0f) return d.y;
+    return stk.pop();
+}
+
+template <bool STATS>
+__device__ __forceinline__ float packed_closest(const TravScene& ts, f3 o, f3 d, int& hitRef, float& hitU, float& hitV, PackedStack& stk, DevStats* dst, TravCount& tc)
+{
+    float distance = kFltMax;
+    hitRef = -1; hitU = 0.0f; hitV = 0.0f;
+    const f3 invdir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    stk.ptr = 0;
+    if (!(ray_box(ts.rootMin[0], ts.rootMin[1], ts.rootMin[2], ts.rootMax[0], ts.rootMax[1], ts.rootMax[2], o, invdir) > 0.0f)) return distance;
+    int cur = ts.rootDesc;
+    while (cur != kDone) {
+        while (cur >= 0) {
+            if (STATS) tc.inner++;
+            cur = inner_step(ts, cur, o, invdir, stk, dst);
+        }
+        if (cur == kDone) break;
+        if (STATS) tc.leaves++;
+        int i = ~cur;
+        bool last;
+        do {
+            const float4* r = reinterpret_cast<const float4*>(ts.tris + i);
+            const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+            last = __builtin_bit_cast(uint32_t, r2.y) != 0u;
+            if (STATS) tc.tris++;
+            const f3 v0 = mk3(r0.x, r0.y, r0.z), e1 = mk3(r0.w, r1.x, r1.y), e2 = mk3(r1.z, r1.w, r2.x);
+            const f3 pvec = cross3(d, e2);
+            const float det = dot3(e1, pvec);
+            if (!(det > -kEpsilon && det < kEpsilon)) {
+                const float invDet = 1.0f / det;
+                const f3 tvec = o - v0;
+                const float u = dot3(tvec, pvec) * invDet;
+                if (!(u < 0.0f || u > 1.0f)) {
+                    const f3 qvec = cross3(tvec, e1);
+                    const float v = dot3(d, qvec) * invDet;
+                    if (!(v < 0.0f || u + v > 1.0f)) {
+                        const float t = dot3(e2, qvec) * invDet;
+                        if (t >= 0.0f && t < distance) { distance = t; hitRef = i; hitU = u; hitV = v; }
+                    }
+                }
+            }
+            i++;
+        } while (!last);
+        cur = stk.pop();
+    }
+    return distance;
+}
+
+template <bool STATS>
+__device__ __forceinline__ bool packed_any(const TravScene& ts, f3 o, f3 d, float lightDistance, PackedStack& stk, DevStats* dst, TravCount& tc)
+{
+    const f3 invdir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    stk.ptr = 0;
+    if (!(ray_box(ts.rootMin[0], ts.rootMin[1], ts.rootMin[2], ts.rootMax[0], ts.rootMax[1], ts.rootMax[2], o, invdir) > 0.0f)) return false;
+    int cur = ts.rootDesc;
+    bool occluded = false;
+    while (cur != kDone) {
+        while (cur >= 0) {
+            if (STATS) tc.inner++;
+            cur = inner_step(ts, cur, o, invdir, stk, dst);
+        }
+        if (cur == kDone) break;
+        if (STATS) tc.leaves++;
+        int i = ~cur;
+        bool last;
+        do {
+            const float4* r = reinterpret_cast<const float4*>(ts.tris + i);
+            const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+            last = __builtin_bit_cast(uint32_t, r2.y) != 0u;
+            if (STATS) tc.tris++;
+            const f3 v0 = mk3(r0.x, r0.y, r0.z), e1 = mk3(r0.w, r1.x, r1.y), e2 = mk3(r1.z, r1.w, r2.x);
+            const f3 pvec = cross3(d, e2);
+            const float det = dot3(e1, pvec);
+            if (!(det > -kEpsilon && det < kEpsilon)) {
+                const float invDet = 1.0f / det;
+                const f3 tvec = o - v0;
+                const float u = dot3(tvec, pvec) * invDet;
+                if (!(u < 0.0f || u > 1.0f)) {
+                    const f3 qvec = cross3(tvec, e1);
+                    const float v = dot3(d, qvec) * invDet;
+                    if (!(v < 0.0f || u + v > 1.0f)) {
+                        const float t = dot3(e2, qvec) * invDet;
+                        if (t > kEpsilon && t < 1.0f / kEpsilon) {
+                            if (length3(d * t) < lightDistance) { occluded = true; last = true; }
+                        }
+                    }
+                }
+            }
+            i++;
+        } while (!last);
+        cur = occluded ? kDone : stk.pop();
+    }
+    return occluded;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kTravBlock) void k_extend(RenderParams p)
+{
+    __shared__ int s_stack[kLdsStack * kTravBlock];
+    const uint32_t gtid = blockIdx.x * kTravBlock + threadIdx.x;
+    const uint32_t stride = gridDim.x * kTravBlock;
+    PackedStack stk; stk.lds = s_stack + threadIdx.x; stk.ovf = p.ovfStack + gtid; stk.ovfStride = p.ovfStride; stk.ptr = 0;
+    TravCount tc = { 0, 0, 0 }; uint32_t rays = 0;
+    const uint32_t count = p.qc[QC_EXT_COUNT];
+    const uint32_t* qExt = p.queues + (size_t)Q_EXT_RAY * p.P;
+    for (uint32_t q = gtid; q < count; q += stride) {
+        const uint32_t index = qExt[q];                                      // extensionRayCast.hlsl:210
+        if (index == kQueueHole) continue;
+        const f3 o = ld3(p, F_RAY_OX, index), d = ld3(p, F_RAY_DX, index);   // :213-214
+        int hitRef; float hu, hv;
+        float distance = packed_closest<STATS>(p.trav, o, d, hitRef, hu, hv, stk, p.stats, tc); // :216
+        if (STATS) rays++;
+        if (distance < kFltMax) {                                            // :218-225
+            st3(p, F_SP_X, index, o + d * distance);                         // :66,71 hitPoint = origin + direction * t
+            st3(p, F_BARY_X, index, mk3(1.0f - hu - hv, hu, hv));            // :72
+            const int4 T = *reinterpret_cast<const int4*>(&p.scene.tris[hitRef]); // :121 state.tri = indices[i]
+            stu(p, F_TRI_0, index, (uint32_t)T.x); stu(p, F_TRI_1, index, (uint32_t)T.y);
+            stu(p, F_TRI_2, index, (uint32_t)T.z); stu(p, F_TRI_MAT, index, (uint32_t)T.w);
+        }
+        uint32_t lightIndex = 0;                                             // rayLightIntersection :168-194
+        const uint32_t lc = p.cam.lightCount < GMUPT_MAX_LIGHTS ? p.cam.lightCount : GMUPT_MAX_LIGHTS;
+        for (uint32_t li = 0; li < lc; li++) {
+            const gmupt_light L = p.scene.lights[li];
+            const f3 position = mk3(L.position[0], L.position[1], L.position[2]) - o;
+            const float radius2 = L.radius * L.radius;
+            const float tca = dot3(position, d);
+            const float d2 = dot3(position, position) - tca * tca;
+            if (d2 > radius2) continue;
+            const float thc = dsqrt(radius2 - d2);
+            float t0 = tca - thc;
+            const float t1 = tca + thc;
+            if (t0 < 0.0f) t0 = t1;
+            if (t0 > 0.0f && t0 < distance) { distance = t0; lightIndex = li + 1; }
+        }
+        stu(p, F_IS_EMITTER, index, lightIndex);                             // :231
+        stf(p, F_HIT_DIST, index, distance);                                 // :232
+    }
+    if (STATS) flush_counts(p.stats, tc, rays, true);
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kTravBlock) void k_shadow(RenderParams p)
+{
+    __shared__ int s_stack[kLdsStack * kTravBlock];
+    const uint32_t gtid = blockIdx.x * kTravBlock + threadIdx.x;
+    const uint32_t stride = gridDim.x * kTravBlock;
+    const uint32_t count = p.qc[QC_SHADOWRAY];                               // shadowRayCast.hlsl:151
+    __syncthreads();
+    if (gtid == 0) {
+        // :144-148: QC[0..3] = (0, QC1 + QC0, 0, 0).  Nothing else in this kernel reads those words.
+        const uint32_t q0 = p.qc[QC_NEWPATH], q1 = p.qc[QC_LASTPATHCNT];
+        p.qc[QC_NEWPATH] = 0; p.qc[QC_LASTPATHCNT] = q0 + q1; p.qc[QC_MATUE4] = 0; p.qc[QC_MATGLASS] = 0;
+    }
+    PackedStack stk; stk.lds = s_stack + threadIdx.x; stk.ovf = p.ovfStack + gtid; stk.ovfStride = p.ovfStride; stk.ptr = 0;
+    TravCount tc = { 0, 0, 0 }; uint32_t rays = 0;
+    const uint32_t* qSh = p.queues + (size_t)Q_SHADOW_RAY * p.P;
+    for (uint32_t q = gtid; q < count; q += stride) {
+        const uint32_t index = qSh[q];                                       // :159
+        const f3 o = ld3(p, F_SH_OX, index), d = ld3(p, F_SH_DX, index);     // :162-163
+        const float lightDistance = ldf(p, F_LIGHT_DIST, index);             // :164
+        const bool inShadow = packed_any<STATS>(p.trav, o, d, lightDistance, stk, p.stats, tc); // :166
+        if (STATS) rays++;
+        stu(p, F_IN_SHADOW, index, inShadow ? 1u : 0u);                      // :167
+    }
+    if (STATS) flush_counts(p.stats, tc, rays, false);
+}
+
+// ------------------------------------------------------------------------------------------------ host launchers
+void launch_extend(const RenderParams& p, uint32_t blocks, bool stats, bool refLayout, hipStream_t s)
+{
+    if (refLayout) {
+        if (stats) hipLaunchKernelGGL(k_extend_ref<true>, dim3(blocks), dim3(kTravBlock), 0, s, p);
+        else hipLaunchKernelGGL(k_extend_ref<false>, dim3(blocks), dim3(kTravBlock), 0, s, p);
+    } else {
+        if (stats) hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(kTravBlock), 0, s, p);
+        else hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(kTravBlock), 0, s, p);
+    }
+}
+void launch_shadow(const RenderParams& p, uint32_t blocks, bool stats, bool refLayout, hipStream_t s)
+{
+    if (refLayout) {
+        if (stats) hipLaunchKernelGGL(k_shadow_ref<true>, dim3(blocks), dim3(kTravBlock), 0, s, p);
+        else hipLaunchKernelGGL(k_shadow_ref<false>, dim3(blocks), dim3(kTravBlock), 0, s, p);
+    } else {
+        if (stats) hipLaunchKernelGGL(k_shadow<true>, dim3(blocks), dim3(kTravBlock), 0, s, p);
+        else hipLaunchKernelGGL(k_shadow<false>, dim3(blocks), dim3(kTravBlock), 0, s, p);
+    }
+}
+uint32_t traversal_block_threads() { return kTravBlock; }
+uint32_t traversal_overflow_entries() { return kMaxStack - kLdsStack; }
+
+} // namespace gmupt
