@@ -234,8 +234,8 @@ extern "C" int gmupt_renderer_create(gmupt_device* dev, const gmupt_renderer_des
     if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.cls, (size_t)P, CLS_ENDED);
     if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.listNext, (size_t)P * 4, 0xFF);
     if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.sample, (size_t)P * 12, 0);
-    if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.blockCounts, (size_t)p.nBlocks * 12, 0);
-    if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.blockOffsets, (size_t)p.nBlocks * 12, 0);
+    if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.blockCounts, (size_t)p.nBlocks * 4 * kNumCounts, 0);
+    if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.blockOffsets, (size_t)p.nBlocks * 4 * kNumCounts, 0);
     if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.queues, (size_t)P * 20, 0);
     if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.qc, 32, 0);
     if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.stats, sizeof(DevStats), 0);

@@ -31,7 +31,8 @@ enum Field : uint32_t {
 static_assert(F_COUNT == 50, "50 words per path");
 
 // per-slot class written by the logic kernel, consumed by the material kernel
-enum SlotClass : uint8_t { CLS_UE4 = 0, CLS_GLASS = 1, CLS_ENDED = 2, CLS_RETIRED = 3, CLS_NONE = 4 };
+enum SlotClass : uint8_t { CLS_UE4 = 0, CLS_GLASS = 1, CLS_ENDED = 2, CLS_RETIRED = 3, CLS_NONE = 4, CLS_MASK = 0x0F, CLS_SHADOW_BIT = 0x10 };
+constexpr int kNumCounts = 4; // per-block counts: UE4, glass, ended, shadow-ray pushers
 
 // queue counters, same indices as the reference (structs.h:62-68); [7] is this build's live extension-queue length
 enum Counter : uint32_t { QC_NEWPATH = 0, QC_LASTPATHCNT = 1, QC_MATUE4 = 2, QC_MATGLASS = 3, QC_EXT_UE4_OFFSET = 4, QC_EXT_GLASS_OFFSET = 5, QC_SHADOWRAY = 6, QC_EXT_COUNT = 7 };
@@ -88,8 +89,8 @@ struct RenderParams {
     uint32_t* listNext;    // P: per-pixel list of paths that ended this iteration
     uint32_t* listHead;    // fbW * fbH
     float* sample;         // 3 * P: tonemapped sample of an ended path
-    uint32_t* blockCounts; // 3 * nBlocks
-    uint32_t* blockOffsets;// 3 * nBlocks
+    uint32_t* blockCounts; // kNumCounts * nBlocks
+    uint32_t* blockOffsets;// kNumCounts * nBlocks
     uint32_t nBlocks;
     uint32_t* queues;      // 5 * P
     uint32_t* qc;          // 8

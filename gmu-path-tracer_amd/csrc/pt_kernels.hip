@@ -58,15 +58,16 @@ __device__ __forceinline__ float powerHeuristic(float rayPdf, float lightPdf) //
 }
 
 // ------------------------------------------------------------------------------------------------ block class counts
-// every thread of the block calls this once; writes blockCounts[k * nBlocks + blockIdx.x] for k = 0..2
+// every thread of the block calls this once; writes blockCounts[k * nBlocks + blockIdx.x] for k = 0..3
+// (k = 3: UE4 slots whose light lies in the upper hemisphere, i.e. the entries of the shadow queue)
 __device__ __forceinline__ void publish_block_counts(const RenderParams& p, int c)
 {
-    __shared__ uint32_t s_cnt[3][kBlock / 64];
+    __shared__ uint32_t s_cnt[kNumCounts][kBlock / 64];
     const uint32_t wave = threadIdx.x >> 6;
-    unsigned long long b0 = __ballot(c == CLS_UE4), b1 = __ballot(c == CLS_GLASS), b2 = __ballot(c == CLS_ENDED);
-    if ((threadIdx.x & 63) == 0) { s_cnt[0][wave] = __popcll(b0); s_cnt[1][wave] = __popcll(b1); s_cnt[2][wave] = __popcll(b2); }
+    unsigned long long b0 = __ballot((c & CLS_MASK) == CLS_UE4), b1 = __ballot(c == CLS_GLASS), b2 = __ballot(c == CLS_ENDED), b3 = __ballot(c == (CLS_UE4 | CLS_SHADOW_BIT));
+    if ((threadIdx.x & 63) == 0) { s_cnt[0][wave] = __popcll(b0); s_cnt[1][wave] = __popcll(b1); s_cnt[2][wave] = __popcll(b2); s_cnt[3][wave] = __popcll(b3); }
     __syncthreads();
-    if (threadIdx.x < 3) {
+    if (threadIdx.x < kNumCounts) {
         uint32_t s = 0;
         for (int w = 0; w < kBlock / 64; w++) s += s_cnt[threadIdx.x][w];
         p.blockCounts[threadIdx.x * p.nBlocks + blockIdx.x] = s;
@@ -171,6 +172,9 @@ __global__ __launch_bounds__(kBlock) void k_logic(RenderParams p)
                 st3(p, F_SH_OX, i, surfacePos);
                 st3(p, F_SH_DX, i, lightDir);
                 stf(p, F_LIGHT_DIST, i, distance - kEpsilonOffset);
+                // materialUE4.hlsl:167: a UE4 slot pushes a shadow ray iff the light direction lies in the normal's hemisphere;
+                // both operands are final here, so the shadow queue can be ranked by the same scan as the material queues
+                if (c == CLS_UE4 && dot3(lightDir, normal) > 0.0f) c |= CLS_SHADOW_BIT;
 
                 st3(p, F_RAD_R, i, radiance);                               // :295
                 st3(p, F_THR_R, i, throughput);                             // :296
@@ -189,11 +193,11 @@ __global__ __launch_bounds__(kBlock) void k_logic(RenderParams p)
 __global__ __launch_bounds__(1024) void k_scan(RenderParams p, int clearFrame)
 {
     __shared__ uint32_t s_part[1024];
-    __shared__ uint32_t s_total[3];
+    __shared__ uint32_t s_total[kNumCounts];
     const uint32_t t = threadIdx.x;
     const uint32_t chunk = (p.nBlocks + 1023u) / 1024u;
     const uint32_t lo = t * chunk, hi = (lo + chunk < p.nBlocks) ? lo + chunk : p.nBlocks;
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < kNumCounts; k++) {
         uint32_t sum = 0;
         for (uint32_t b = lo; b < hi; b++) sum += p.blockCounts[k * p.nBlocks + b];
         s_part[t] = sum;
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(1024) void k_scan(RenderParams p, int clearFrame)
         p.qc[QC_MATGLASS] = nGlass;
         p.qc[QC_EXT_UE4_OFFSET] = qc0;                              // newPath.hlsl:57
         p.qc[QC_EXT_GLASS_OFFSET] = qc0 + nUE4;                     // newPath.hlsl:58
-        p.qc[QC_SHADOWRAY] = 0;                                     // newPath.hlsl:59
+        p.qc[QC_SHADOWRAY] = s_total[3];                           // newPath.hlsl:59 resets it, materialUE4.hlsl:173 counts it up to this total
         p.qc[QC_EXT_COUNT] = nNew + nUE4 + nGlass;
         uint32_t gen = nNew;
         if (p.budget) { uint32_t remaining = p.budget > lastPath ? p.budget - lastPath : 0u; if (gen > remaining) gen = remaining; }
@@ -302,7 +306,7 @@ __device__ __forceinline__ f3 ue4Evaluate(const Ue4State& st, f3 direction) // m
                (st.baseColor.z / kPi) * om + (D * F.z * G) / den);           // :114
 }
 
-__device__ __forceinline__ void stage_ue4(const RenderParams& p, uint32_t queueIndex, uint32_t index) // materialUE4.hlsl:118-192
+__device__ __forceinline__ void stage_ue4(const RenderParams& p, uint32_t queueIndex, uint32_t index, uint32_t shadowRank) // materialUE4.hlsl:118-192
 {
     Rng g; g.seed(queueIndex, p.cam.randomSeed[0], p.cam.randomSeed[1]);   // :131
     Ue4State st;
@@ -338,9 +342,8 @@ __device__ __forceinline__ void stage_ue4(const RenderParams& p, uint32_t queueI
         const float lc = (float)p.cam.lightCount;
         const float fo = lightFalloff(distance, L.falloff);
         st3(p, F_DL_R, index, mk3(ph * e.x * L.emission[0] * lc * fo, ph * e.y * L.emission[1] * lc * fo, ph * e.z * L.emission[2] * lc * fo)); // :187-188
-        // shadow queue: its order does not influence any result (shadowRayCast has no RNG), so a plain atomic
-        // (hipcc aggregates it to one add per wave) replaces the ballot + lane-0 InterlockedAdd of :168-176
-        const uint32_t pos = atomicAdd(&p.qc[QC_SHADOWRAY], 1u);
+        // :168-176,189: shadow queue slot = rank among the UE4 slots that push one (canonical order, no atomics)
+        const uint32_t pos = shadowRank;
         p.queues[(size_t)Q_SHADOW_RAY * p.P + pos] = index;                  // :189
     }
 }
@@ -442,12 +445,14 @@ __device__ __forceinline__ void stage_new_path(const RenderParams& p, uint32_t q
 
 __global__ __launch_bounds__(kBlock) void k_material(RenderParams p, int clearFrame)
 {
-    __shared__ uint32_t s_cnt[3][kBlock / 64];
+    __shared__ uint32_t s_cnt[kNumCounts][kBlock / 64];
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t wave = threadIdx.x >> 6;
-    const int c = (i < p.L) ? (int)p.cls[i] : (int)CLS_NONE;
-    const unsigned long long b0 = __ballot(c == CLS_UE4), b1 = __ballot(c == CLS_GLASS), b2 = __ballot(c == CLS_ENDED);
-    if ((threadIdx.x & 63) == 0) { s_cnt[0][wave] = __popcll(b0); s_cnt[1][wave] = __popcll(b1); s_cnt[2][wave] = __popcll(b2); }
+    const int cfull = (i < p.L) ? (int)p.cls[i] : (int)CLS_NONE;
+    const int c = cfull & CLS_MASK;
+    const bool shadow = cfull == (CLS_UE4 | CLS_SHADOW_BIT);
+    const unsigned long long b0 = __ballot(c == CLS_UE4), b1 = __ballot(c == CLS_GLASS), b2 = __ballot(c == CLS_ENDED), b3 = __ballot(shadow);
+    if ((threadIdx.x & 63) == 0) { s_cnt[0][wave] = __popcll(b0); s_cnt[1][wave] = __popcll(b1); s_cnt[2][wave] = __popcll(b2); s_cnt[3][wave] = __popcll(b3); }
     __syncthreads();
     if (c > CLS_ENDED) return;
     // rank = slots of the same class with a smaller index: block offset + earlier waves + lower lanes
@@ -458,7 +463,14 @@ __global__ __launch_bounds__(kBlock) void k_material(RenderParams p, int clearFr
     if (c == CLS_ENDED) stage_new_path(p, rank, i, clearFrame);
     else {
         p.queues[(size_t)(c == CLS_UE4 ? Q_MAT_UE4 : Q_MAT_GLASS) * p.P + rank] = i; // logic.hlsl:282-285
-        if (c == CLS_UE4) stage_ue4(p, rank, i); else stage_glass(p, rank, i);
+        if (c == CLS_UE4) {
+            uint32_t srank = 0;
+            if (shadow) {
+                srank = p.blockOffsets[3 * p.nBlocks + blockIdx.x] + prefix_rank(b3);
+                for (uint32_t w = 0; w < wave; w++) srank += s_cnt[3][w];
+            }
+            stage_ue4(p, rank, i, srank);
+        } else stage_glass(p, rank, i);
     }
 }
 
