@@ -150,7 +150,9 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(per_launch), "avg_launch_ms": round(ext_ms, 4),
                     "rays_per_launch": s2.ext_rays / max(args.steps, 1),
-                    "inner_per_ray": round(s2.ext_inner / max(s2.ext_rays, 1), 2), "tris_per_ray": round(s2.ext_tris / max(s2.ext_rays, 1), 2)}
+                    "inner_per_ray": round(s2.ext_inner / max(s2.ext_rays, 1), 2), "tris_per_ray": round(s2.ext_tris / max(s2.ext_rays, 1), 2),
+                    "simd_efficiency": {"inner": round(s2.ext_inner / max(64 * s2.ext_wave_inner, 1), 3), "triangles": round(s2.ext_tris / max(64 * s2.ext_wave_tris, 1), 3),
+                                        "shadow_inner": round(s2.sh_inner / max(64 * s2.sh_wave_inner, 1), 3), "shadow_triangles": round(s2.sh_tris / max(64 * s2.sh_wave_tris, 1), 3)}}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

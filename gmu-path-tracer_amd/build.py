@@ -33,7 +33,8 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-x", "hip"] + [os.path.join(HERE, s) for s in DEVICE_SOURCES + HOST_SOURCES] + ["-o", LIB]
+    extra = os.environ.get("GMUPT_EXTRA_FLAGS", "").split()
+    cmd = [hipcc] + FLAGS + extra + ["-x", "hip"] + [os.path.join(HERE, s) for s in DEVICE_SOURCES + HOST_SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=HERE)

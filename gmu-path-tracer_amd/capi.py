@@ -53,7 +53,8 @@ class Stats(C.Structure):
                 ("ext_rays", C.c_uint64), ("ext_inner", C.c_uint64), ("ext_leaves", C.c_uint64), ("ext_tris", C.c_uint64),
                 ("sh_rays", C.c_uint64), ("sh_inner", C.c_uint64), ("sh_leaves", C.c_uint64), ("sh_tris", C.c_uint64),
                 ("ms_logic", C.c_double), ("ms_scan", C.c_double), ("ms_accumulate", C.c_double), ("ms_material", C.c_double),
-                ("ms_extend", C.c_double), ("ms_shadow", C.c_double), ("timed_iterations", C.c_uint64)]
+                ("ms_extend", C.c_double), ("ms_shadow", C.c_double), ("timed_iterations", C.c_uint64),
+                ("ext_wave_inner", C.c_uint64), ("ext_wave_tris", C.c_uint64), ("sh_wave_inner", C.c_uint64), ("sh_wave_tris", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -32,8 +32,8 @@ void launch_clear(const RenderParams& p, hipStream_t s);
 void launch_logic(const RenderParams& p, hipStream_t s);
 void launch_scan(const RenderParams& p, int clearFrame, hipStream_t s);
 void launch_material(const RenderParams& p, int clearFrame, hipStream_t s);
-void launch_extend(const RenderParams& p, uint32_t blocks, bool stats, bool refLayout, hipStream_t s);
-void launch_shadow(const RenderParams& p, uint32_t blocks, bool stats, bool refLayout, hipStream_t s);
+void launch_extend(const RenderParams& p, uint32_t blocks, bool stats, int mode, hipStream_t s);
+void launch_shadow(const RenderParams& p, uint32_t blocks, bool stats, int mode, hipStream_t s);
 void launch_detmath(int fn, const float* x, const float* y, float* out, uint32_t n, hipStream_t s);
 uint32_t traversal_block_threads();
 uint32_t traversal_overflow_entries();
@@ -162,7 +162,7 @@ struct gmupt_renderer {
     std::vector<void*> allocs;
     // packed traversal copy of the bound scene
     void* travNodes = nullptr; void* travTris = nullptr;
-    bool refTraversal = false; // GMUPT_TRAVERSAL=ref: ray casts straight on the reference-layout buffers (A/B timing)
+    int travMode = 4; // GMUPT_TRAVERSAL (A/B timing): default "ifif1" interleaved persistent lanes | "ififN" tuning variants | "whilewhile" | "static" one ray per lane | "ref" reference-layout buffers
 };
 
 static int dev_alloc(gmupt_renderer* r, void** ptr, size_t bytes, int fill)
@@ -209,7 +209,7 @@ extern "C" int gmupt_renderer_create(gmupt_device* dev, const gmupt_renderer_des
     gmupt_renderer* r = new (std::nothrow) gmupt_renderer();
     if (!r) return fail(GMUPT_ERR_OUT_OF_MEMORY, "gmupt_renderer_create: out of host memory");
     r->dev = dev; r->desc = *desc;
-    { const char* tv = std::getenv("GMUPT_TRAVERSAL"); r->refTraversal = tv && std::strcmp(tv, "ref") == 0; }
+    { const char* tv = std::getenv("GMUPT_TRAVERSAL"); r->travMode = !tv ? 4 : (std::strcmp(tv, "ref") == 0 ? 1 : (std::strcmp(tv, "static") == 0 ? 2 : (std::strncmp(tv, "ifif", 4) == 0 ? 3 + std::atoi(tv + 4) : (std::strcmp(tv, "whilewhile") == 0 ? 0 : 4)))); }
     if (r->desc.pool_paths == 0) r->desc.pool_paths = GMUPT_PATHCOUNT;
     if (r->desc.live_paths == 0 || r->desc.live_paths > r->desc.pool_paths) r->desc.live_paths = r->desc.pool_paths;
     const uint32_t P = r->desc.pool_paths, L = r->desc.live_paths;
@@ -227,6 +227,7 @@ extern "C" int gmupt_renderer_create(gmupt_device* dev, const gmupt_renderer_des
     const uint32_t tb = traversal_block_threads();
     r->travBlocks = (L + tb - 1) / tb;
     p.ovfStride = r->travBlocks * tb;
+    { const char* rw = std::getenv("GMUPT_RAYS_PER_WAVE"); p.raysPerWave = rw ? (uint32_t)std::atoi(rw) : 512u; if (p.raysPerWave < 64) p.raysPerWave = 64; }
 
     int rc = GMUPT_OK;
     // Renderer::createBuffers creates the UAV buffers without initial data: D3D11 zero-initialises them
@@ -394,8 +395,8 @@ static int run_iteration(gmupt_renderer* r, bool doShade, bool doExtend, bool do
         launch_material(p, clearFrame, r->stream);
         if (ev) HIP_TRY(hipEventRecord(ev->e[3], r->stream));
     }
-    if (doExtend) { launch_extend(p, r->travBlocks, stats, r->refTraversal, r->stream); if (ev) HIP_TRY(hipEventRecord(ev->e[4], r->stream)); }
-    if (doShadow) { launch_shadow(p, r->travBlocks, stats, r->refTraversal, r->stream); if (ev) HIP_TRY(hipEventRecord(ev->e[5], r->stream)); }
+    if (doExtend) { launch_extend(p, r->travBlocks, stats, r->travMode, r->stream); if (ev) HIP_TRY(hipEventRecord(ev->e[4], r->stream)); }
+    if (doShadow) { launch_shadow(p, r->travBlocks, stats, r->travMode, r->stream); if (ev) HIP_TRY(hipEventRecord(ev->e[5], r->stream)); }
     HIP_TRY(hipGetLastError());
     return GMUPT_OK;
 }
@@ -496,6 +497,7 @@ extern "C" int gmupt_get_stats(gmupt_renderer* r, gmupt_stats* out)
     out->ms_accumulate = 0.0; // accumulation is fused into the material kernel
     out->ms_extend = r->msStage[3]; out->ms_shadow = r->msStage[4];
     out->timed_iterations = r->timedIters;
+    out->ext_wave_inner = ds.extWaveInner; out->ext_wave_tris = ds.extWaveTris; out->sh_wave_inner = ds.shWaveInner; out->sh_wave_tris = ds.shWaveTris;
     return GMUPT_OK;
 }
 

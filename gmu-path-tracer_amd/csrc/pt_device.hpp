@@ -47,6 +47,7 @@ struct DevStats {
     unsigned long long pathsGenerated, pathsCompleted, segments;
     unsigned long long extRays, extInner, extLeaves, extTris;
     unsigned long long shRays, shInner, shLeaves, shTris;
+    unsigned long long extWaveInner, extWaveTris, shWaveInner, shWaveTris; // wave-level loop iterations (SIMD efficiency = lane steps / (64 * wave iterations))
     uint32_t activePaths;
     uint32_t stackOverflow; // traversal needed more than the provisioned stack (results then differ from an unbounded stack)
 };
@@ -101,6 +102,7 @@ struct RenderParams {
     uint32_t budget, maxDepth;
     int* ovfStack;         // global overflow of the traversal stacks
     uint32_t ovfStride;    // threads of the traversal grid
+    uint32_t raysPerWave;  // queue entries owned by one wave of the persistent ray-cast kernels
     gmupt_camera_buffer cam;
     SceneView scene;
     TravScene trav;

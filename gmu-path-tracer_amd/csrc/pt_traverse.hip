@@ -294,6 +294,9 @@ __device__ __forceinline__ int inner_step(const TravScene& ts, int cur, f3 o, f3
     const float4* n = reinterpret_cast<const float4*>(ts.nodes + cur);
     const float4 a = n[0], b = n[1], c = n[2];
     const int4 d = *reinterpret_cast<const int4*>(n + 3);
+#ifdef GMUPT_EXPERIMENT_EXTRA_LOAD
+    { const volatile float4* vn = reinterpret_cast<const volatile float4*>(n); float ex = vn[0].x; float ey = vn[2].y; asm volatile("" :: "v"(ex), "v"(ey)); }
+#endif
     const float leftHit = ray_box(a.x, a.y, a.z, a.w, b.x, b.y, o, invdir);
     const float rightHit = ray_box(b.z, b.w, c.x, c.y, c.z, c.w, o, invdir);
     if (leftHit > 0.0f && rightHit > 0.0f) {
@@ -470,10 +473,434 @@ __global__ __launch_bounds__(kTravBlock) void k_shadow(RenderParams p)
     if (STATS) flush_counts(p.stats, tc, rays, false);
 }
 
-// ------------------------------------------------------------------------------------------------ host launchers
-void launch_extend(const RenderParams& p, uint32_t blocks, bool stats, bool refLayout, hipStream_t s)
+
+__device__ __forceinline__ void flush_wave_iters(DevStats* st, uint32_t wIn, uint32_t wTr, bool ext)
 {
-    if (refLayout) {
+    uint32_t a = wIn, b = wTr;
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+    if ((threadIdx.x & 63) == 0) {
+        if (ext) { atomicAdd(&st->extWaveInner, (unsigned long long)a); atomicAdd(&st->extWaveTris, (unsigned long long)b); }
+        else { atomicAdd(&st->shWaveInner, (unsigned long long)a); atomicAdd(&st->shWaveTris, (unsigned long long)b); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ persistent-lane variants
+// Rays differ a lot in length (no pruning: a ray visits every box its whole line pierces), so with one ray per lane a wave64
+// spends most of its time waiting for its longest ray (measured VALU lane utilisation of the kernels above: 12 %).
+// Here a wave owns a contiguous chunk of the queue and hands a new ray to a lane as soon as enough lanes are idle
+// (Aila & Laine style lane refill, wave64 ballot + mbcnt ranks, no atomics: the chunk is private to the wave).
+// Per-ray arithmetic and visit order are unchanged, so results are identical.
+constexpr uint32_t kRaysPerWave = 256;   // queue entries owned by one wave
+constexpr int kRefillThreshold = 20;     // refill when at least this many lanes are idle
+
+template <bool STATS>
+__global__ __launch_bounds__(kTravBlock) void k_extend_p(RenderParams p)
+{
+    __shared__ int s_stack[kLdsStack * kTravBlock];
+    const uint32_t gtid = blockIdx.x * kTravBlock + threadIdx.x;
+    PackedStack stk; stk.lds = s_stack + threadIdx.x; stk.ovf = p.ovfStack + gtid; stk.ovfStride = p.ovfStride; stk.ptr = 0;
+    TravCount tc = { 0, 0, 0 }; uint32_t rays = 0; uint32_t wIn = 0, wTr = 0;
+    const TravScene& ts = p.trav;
+    const uint32_t count = p.qc[QC_EXT_COUNT];
+    const uint32_t* qExt = p.queues + (size_t)Q_EXT_RAY * p.P;
+    uint32_t next = (gtid >> 6) * kRaysPerWave;
+    const uint32_t end = (next + kRaysPerWave < count) ? next + kRaysPerWave : count;
+    if (next >= end) return; // wave-uniform
+
+    bool haveRay = false;
+    uint32_t index = 0;
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), invdir = mk3(0, 0, 0);
+    float distance = kFltMax, hu = 0.0f, hv = 0.0f;
+    int hitRef = -1;
+    int cur = kDone;
+
+    for (;;) {
+        const bool idle = (cur == kDone);
+        const unsigned long long idleMask = __ballot(idle);
+        const int nIdle = __popcll(idleMask);
+        if (nIdle == 64 || (nIdle >= kRefillThreshold && next < end)) { // wave-uniform
+            if (idle) {
+                if (haveRay) {
+                    // finish the ray: extensionRayCast.hlsl:218-232
+                    if (distance < kFltMax) {
+                        st3(p, F_SP_X, index, o + d * distance);
+                        st3(p, F_BARY_X, index, mk3(1.0f - hu - hv, hu, hv));
+                        const int4 T = *reinterpret_cast<const int4*>(&p.scene.tris[hitRef]);
+                        stu(p, F_TRI_0, index, (uint32_t)T.x); stu(p, F_TRI_1, index, (uint32_t)T.y);
+                        stu(p, F_TRI_2, index, (uint32_t)T.z); stu(p, F_TRI_MAT, index, (uint32_t)T.w);
+                    }
+                    uint32_t lightIndex = 0;
+                    const uint32_t lc = p.cam.lightCount < GMUPT_MAX_LIGHTS ? p.cam.lightCount : GMUPT_MAX_LIGHTS;
+                    for (uint32_t li = 0; li < lc; li++) {
+                        const gmupt_light L = p.scene.lights[li];
+                        const f3 position = mk3(L.position[0], L.position[1], L.position[2]) - o;
+                        const float radius2 = L.radius * L.radius;
+                        const float tca = dot3(position, d);
+                        const float d2 = dot3(position, position) - tca * tca;
+                        if (d2 > radius2) continue;
+                        const float thc = dsqrt(radius2 - d2);
+                        float t0 = tca - thc;
+                        const float t1 = tca + thc;
+                        if (t0 < 0.0f) t0 = t1;
+                        if (t0 > 0.0f && t0 < distance) { distance = t0; lightIndex = li + 1; }
+                    }
+                    stu(p, F_IS_EMITTER, index, lightIndex);
+                    stf(p, F_HIT_DIST, index, distance);
+                    haveRay = false;
+                }
+                const uint32_t my = next + prefix_rank(idleMask);
+                if (my < end) {
+                    index = qExt[my];
+                    if (index != kQueueHole) {
+                        haveRay = true;
+                        if (STATS) rays++;
+                        o = ld3(p, F_RAY_OX, index); d = ld3(p, F_RAY_DX, index);
+                        invdir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        distance = kFltMax; hitRef = -1; hu = 0.0f; hv = 0.0f;
+                        stk.ptr = 0;
+                        cur = (ray_box(ts.rootMin[0], ts.rootMin[1], ts.rootMin[2], ts.rootMax[0], ts.rootMax[1], ts.rootMax[2], o, invdir) > 0.0f) ? ts.rootDesc : kDone;
+                    }
+                }
+            }
+            if (nIdle == 64 && next >= end) break; // nothing in flight and the chunk is exhausted (wave-uniform)
+            next = (next + (uint32_t)nIdle < end) ? next + (uint32_t)nIdle : end;
+        }
+        while (cur >= 0) {
+            if (STATS) { tc.inner++; if (prefix_rank(__ballot(1)) == 0) wIn++; }
+            cur = inner_step(ts, cur, o, invdir, stk, p.stats);
+        }
+        if (cur != kDone) {
+            if (STATS) tc.leaves++;
+            int i = ~cur;
+            bool last;
+            do {
+                const float4* r = reinterpret_cast<const float4*>(ts.tris + i);
+                const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+                last = __builtin_bit_cast(uint32_t, r2.y) != 0u;
+                if (STATS) { tc.tris++; if (prefix_rank(__ballot(1)) == 0) wTr++; }
+                const f3 v0 = mk3(r0.x, r0.y, r0.z), e1 = mk3(r0.w, r1.x, r1.y), e2 = mk3(r1.z, r1.w, r2.x);
+                const f3 pvec = cross3(d, e2);
+                const float det = dot3(e1, pvec);
+                if (!(det > -kEpsilon && det < kEpsilon)) {
+                    const float invDet = 1.0f / det;
+                    const f3 tvec = o - v0;
+                    const float u = dot3(tvec, pvec) * invDet;
+                    if (!(u < 0.0f || u > 1.0f)) {
+                        const f3 qvec = cross3(tvec, e1);
+                        const float v = dot3(d, qvec) * invDet;
+                        if (!(v < 0.0f || u + v > 1.0f)) {
+                            const float t = dot3(e2, qvec) * invDet;
+                            if (t >= 0.0f && t < distance) { distance = t; hitRef = i; hu = u; hv = v; }
+                        }
+                    }
+                }
+                i++;
+            } while (!last);
+            cur = stk.pop();
+        }
+    }
+    if (STATS) { flush_counts(p.stats, tc, rays, true); flush_wave_iters(p.stats, wIn, wTr, true); }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kTravBlock) void k_shadow_p(RenderParams p)
+{
+    __shared__ int s_stack[kLdsStack * kTravBlock];
+    const uint32_t gtid = blockIdx.x * kTravBlock + threadIdx.x;
+    const uint32_t count = p.qc[QC_SHADOWRAY];                               // shadowRayCast.hlsl:151
+    __syncthreads();
+    if (gtid == 0) {
+        // :144-148: QC[0..3] = (0, QC1 + QC0, 0, 0).  Nothing else in this kernel reads those words.
+        const uint32_t q0 = p.qc[QC_NEWPATH], q1 = p.qc[QC_LASTPATHCNT];
+        p.qc[QC_NEWPATH] = 0; p.qc[QC_LASTPATHCNT] = q0 + q1; p.qc[QC_MATUE4] = 0; p.qc[QC_MATGLASS] = 0;
+    }
+    PackedStack stk; stk.lds = s_stack + threadIdx.x; stk.ovf = p.ovfStack + gtid; stk.ovfStride = p.ovfStride; stk.ptr = 0;
+    TravCount tc = { 0, 0, 0 }; uint32_t rays = 0; uint32_t wIn = 0, wTr = 0;
+    const TravScene& ts = p.trav;
+    const uint32_t* qSh = p.queues + (size_t)Q_SHADOW_RAY * p.P;
+    uint32_t next = (gtid >> 6) * kRaysPerWave;
+    const uint32_t end = (next + kRaysPerWave < count) ? next + kRaysPerWave : count;
+    if (next >= end) return;
+
+    bool haveRay = false, occluded = false;
+    uint32_t index = 0;
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), invdir = mk3(0, 0, 0);
+    float lightDistance = 0.0f;
+    int cur = kDone;
+
+    for (;;) {
+        const bool idle = (cur == kDone);
+        const unsigned long long idleMask = __ballot(idle);
+        const int nIdle = __popcll(idleMask);
+        if (nIdle == 64 || (nIdle >= kRefillThreshold && next < end)) {
+            if (idle) {
+                if (haveRay) { stu(p, F_IN_SHADOW, index, occluded ? 1u : 0u); haveRay = false; } // :167
+                const uint32_t my = next + prefix_rank(idleMask);
+                if (my < end) {
+                    index = qSh[my];                                         // :159
+                    haveRay = true; occluded = false;
+                    if (STATS) rays++;
+                    o = ld3(p, F_SH_OX, index); d = ld3(p, F_SH_DX, index);  // :162-163
+                    lightDistance = ldf(p, F_LIGHT_DIST, index);             // :164
+                    invdir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    stk.ptr = 0;
+                    cur = (ray_box(ts.rootMin[0], ts.rootMin[1], ts.rootMin[2], ts.rootMax[0], ts.rootMax[1], ts.rootMax[2], o, invdir) > 0.0f) ? ts.rootDesc : kDone;
+                }
+            }
+            if (nIdle == 64 && next >= end) break;
+            next = (next + (uint32_t)nIdle < end) ? next + (uint32_t)nIdle : end;
+        }
+        while (cur >= 0) {
+            if (STATS) { tc.inner++; if (prefix_rank(__ballot(1)) == 0) wIn++; }
+            cur = inner_step(ts, cur, o, invdir, stk, p.stats);
+        }
+        if (cur != kDone) {
+            if (STATS) tc.leaves++;
+            int i = ~cur;
+            bool last;
+            do {
+                const float4* r = reinterpret_cast<const float4*>(ts.tris + i);
+                const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+                last = __builtin_bit_cast(uint32_t, r2.y) != 0u;
+                if (STATS) { tc.tris++; if (prefix_rank(__ballot(1)) == 0) wTr++; }
+                const f3 v0 = mk3(r0.x, r0.y, r0.z), e1 = mk3(r0.w, r1.x, r1.y), e2 = mk3(r1.z, r1.w, r2.x);
+                const f3 pvec = cross3(d, e2);
+                const float det = dot3(e1, pvec);
+                if (!(det > -kEpsilon && det < kEpsilon)) {
+                    const float invDet = 1.0f / det;
+                    const f3 tvec = o - v0;
+                    const float u = dot3(tvec, pvec) * invDet;
+                    if (!(u < 0.0f || u > 1.0f)) {
+                        const f3 qvec = cross3(tvec, e1);
+                        const float v = dot3(d, qvec) * invDet;
+                        if (!(v < 0.0f || u + v > 1.0f)) {
+                            const float t = dot3(e2, qvec) * invDet;
+                            if (t > kEpsilon && t < 1.0f / kEpsilon) {
+                                if (length3(d * t) < lightDistance) { occluded = true; last = true; }
+                            }
+                        }
+                    }
+                }
+                i++;
+            } while (!last);
+            cur = occluded ? kDone : stk.pop();
+        }
+    }
+    if (STATS) { flush_counts(p.stats, tc, rays, false); flush_wave_iters(p.stats, wIn, wTr, false); }
+}
+
+// ------------------------------------------------------------------------------------------------ interleaved (if-if) variants
+// One unit of work per lane and loop iteration: an inner step OR one triangle test.  The while-while form above keeps lanes
+// waiting at their leaf until the slowest lane of the wave has finished descending (measured lane utilisation 18 % in the
+// inner loop, 32 % in the triangle loop); here a lane with a ray always has something to do.  `cur` alone carries the state:
+// >= 0 inner node, kDone nothing, otherwise ~index of the NEXT triangle record of the current leaf.
+
+// Moeller-Trumbore on a packed record (extensionRayCast.hlsl:38-62 == shadowRayCast.hlsl:16-40); returns false on a miss
+__device__ __forceinline__ bool tri_test(const Tri48* tris, int i, f3 o, f3 d, float& t, float& u, float& v, bool& last)
+{
+    const float4* r = reinterpret_cast<const float4*>(tris + i);
+    const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+    last = __builtin_bit_cast(uint32_t, r2.y) != 0u;
+    const f3 v0 = mk3(r0.x, r0.y, r0.z), e1 = mk3(r0.w, r1.x, r1.y), e2 = mk3(r1.z, r1.w, r2.x);
+    const f3 pvec = cross3(d, e2);
+    const float det = dot3(e1, pvec);
+    if (det > -kEpsilon && det < kEpsilon) return false;
+    const float invDet = 1.0f / det;
+    const f3 tvec = o - v0;
+    u = dot3(tvec, pvec) * invDet;
+    if (u < 0.0f || u > 1.0f) return false;
+    const f3 qvec = cross3(tvec, e1);
+    v = dot3(d, qvec) * invDet;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    t = dot3(e2, qvec) * invDet;
+    return true;
+}
+
+template <bool STATS, int REPS, int REFILL>
+__global__ __launch_bounds__(kTravBlock) void k_extend_i(RenderParams p)
+{
+    __shared__ int s_stack[kLdsStack * kTravBlock];
+    const uint32_t gtid = blockIdx.x * kTravBlock + threadIdx.x;
+    PackedStack stk; stk.lds = s_stack + threadIdx.x; stk.ovf = p.ovfStack + gtid; stk.ovfStride = p.ovfStride; stk.ptr = 0;
+    TravCount tc = { 0, 0, 0 }; uint32_t rays = 0, wIn = 0, wTr = 0;
+    const TravScene& ts = p.trav;
+    const uint32_t count = p.qc[QC_EXT_COUNT];
+    const uint32_t* qExt = p.queues + (size_t)Q_EXT_RAY * p.P;
+    uint32_t next = (gtid >> 6) * p.raysPerWave;
+    const uint32_t end = (next + p.raysPerWave < count) ? next + p.raysPerWave : count;
+    if (next >= end) return; // wave-uniform
+
+    bool haveRay = false;
+    uint32_t index = 0;
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), invdir = mk3(0, 0, 0);
+    float distance = kFltMax, hu = 0.0f, hv = 0.0f;
+    int hitRef = -1;
+    int cur = kDone;
+
+    for (;;) {
+        const bool idle = (cur == kDone);
+        const unsigned long long idleMask = __ballot(idle);
+        const int nIdle = __popcll(idleMask);
+        if (nIdle == 64 || (nIdle >= REFILL && next < end)) { // wave-uniform
+            if (idle) {
+                if (haveRay) {
+                    // finish the ray: extensionRayCast.hlsl:218-232
+                    if (distance < kFltMax) {
+                        st3(p, F_SP_X, index, o + d * distance);
+                        st3(p, F_BARY_X, index, mk3(1.0f - hu - hv, hu, hv));
+                        const int4 T = *reinterpret_cast<const int4*>(&p.scene.tris[hitRef]);
+                        stu(p, F_TRI_0, index, (uint32_t)T.x); stu(p, F_TRI_1, index, (uint32_t)T.y);
+                        stu(p, F_TRI_2, index, (uint32_t)T.z); stu(p, F_TRI_MAT, index, (uint32_t)T.w);
+                    }
+                    uint32_t lightIndex = 0;
+                    const uint32_t lc = p.cam.lightCount < GMUPT_MAX_LIGHTS ? p.cam.lightCount : GMUPT_MAX_LIGHTS;
+                    for (uint32_t li = 0; li < lc; li++) {
+                        const gmupt_light L = p.scene.lights[li];
+                        const f3 position = mk3(L.position[0], L.position[1], L.position[2]) - o;
+                        const float radius2 = L.radius * L.radius;
+                        const float tca = dot3(position, d);
+                        const float d2 = dot3(position, position) - tca * tca;
+                        if (d2 > radius2) continue;
+                        const float thc = dsqrt(radius2 - d2);
+                        float t0 = tca - thc;
+                        const float t1 = tca + thc;
+                        if (t0 < 0.0f) t0 = t1;
+                        if (t0 > 0.0f && t0 < distance) { distance = t0; lightIndex = li + 1; }
+                    }
+                    stu(p, F_IS_EMITTER, index, lightIndex);
+                    stf(p, F_HIT_DIST, index, distance);
+                    haveRay = false;
+                }
+                const uint32_t my = next + prefix_rank(idleMask);
+                if (my < end) {
+                    index = qExt[my];
+                    if (index != kQueueHole) {
+                        haveRay = true;
+                        if (STATS) rays++;
+                        o = ld3(p, F_RAY_OX, index); d = ld3(p, F_RAY_DX, index);
+                        invdir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        distance = kFltMax; hitRef = -1; hu = 0.0f; hv = 0.0f;
+                        stk.ptr = 0;
+                        cur = (ray_box(ts.rootMin[0], ts.rootMin[1], ts.rootMin[2], ts.rootMax[0], ts.rootMax[1], ts.rootMax[2], o, invdir) > 0.0f) ? ts.rootDesc : kDone;
+                        if (STATS) { if (cur < 0 && cur != kDone) tc.leaves++; }
+                    }
+                }
+            }
+            if (nIdle == 64 && next >= end) break; // nothing in flight and the chunk is exhausted (wave-uniform)
+            next = (next + (uint32_t)nIdle < end) ? next + (uint32_t)nIdle : end;
+        }
+        bool stepped = false;
+#pragma unroll
+        for (int rep = 0; rep < REPS; rep++) {
+            if (cur >= 0) {
+                if (STATS) { tc.inner++; if (prefix_rank(__ballot(1)) == 0) wIn++; }
+                cur = inner_step(ts, cur, o, invdir, stk, p.stats);
+                if (STATS) { if (cur < 0 && cur != kDone) tc.leaves++; }
+                stepped = true;
+            }
+        }
+        if (!stepped && cur != kDone) {
+            if (STATS) { tc.tris++; if (prefix_rank(__ballot(1)) == 0) wTr++; }
+            const int i = ~cur;
+            float t = 0.0f, u = 0.0f, v = 0.0f; bool last;
+            if (tri_test(ts.tris, i, o, d, t, u, v, last)) {
+                if (t >= 0.0f && t < distance) { distance = t; hitRef = i; hu = u; hv = v; } // extensionRayCast.hlsl:64-74
+            }
+            cur = last ? stk.pop() : ~(i + 1);
+            if (STATS) { if (last && cur < 0 && cur != kDone) tc.leaves++; }
+        }
+    }
+    if (STATS) { flush_counts(p.stats, tc, rays, true); flush_wave_iters(p.stats, wIn, wTr, true); }
+}
+
+template <bool STATS, int REPS, int REFILL>
+__global__ __launch_bounds__(kTravBlock) void k_shadow_i(RenderParams p)
+{
+    __shared__ int s_stack[kLdsStack * kTravBlock];
+    const uint32_t gtid = blockIdx.x * kTravBlock + threadIdx.x;
+    const uint32_t count = p.qc[QC_SHADOWRAY];                               // shadowRayCast.hlsl:151
+    __syncthreads();
+    if (gtid == 0) {
+        // :144-148: QC[0..3] = (0, QC1 + QC0, 0, 0).  Nothing else in this kernel reads those words.
+        const uint32_t q0 = p.qc[QC_NEWPATH], q1 = p.qc[QC_LASTPATHCNT];
+        p.qc[QC_NEWPATH] = 0; p.qc[QC_LASTPATHCNT] = q0 + q1; p.qc[QC_MATUE4] = 0; p.qc[QC_MATGLASS] = 0;
+    }
+    PackedStack stk; stk.lds = s_stack + threadIdx.x; stk.ovf = p.ovfStack + gtid; stk.ovfStride = p.ovfStride; stk.ptr = 0;
+    TravCount tc = { 0, 0, 0 }; uint32_t rays = 0, wIn = 0, wTr = 0;
+    const TravScene& ts = p.trav;
+    const uint32_t* qSh = p.queues + (size_t)Q_SHADOW_RAY * p.P;
+    uint32_t next = (gtid >> 6) * p.raysPerWave;
+    const uint32_t end = (next + p.raysPerWave < count) ? next + p.raysPerWave : count;
+    if (next >= end) return;
+
+    bool haveRay = false, occluded = false;
+    uint32_t index = 0;
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), invdir = mk3(0, 0, 0);
+    float lightDistance = 0.0f;
+    int cur = kDone;
+
+    for (;;) {
+        const bool idle = (cur == kDone);
+        const unsigned long long idleMask = __ballot(idle);
+        const int nIdle = __popcll(idleMask);
+        if (nIdle == 64 || (nIdle >= REFILL && next < end)) {
+            if (idle) {
+                if (haveRay) { stu(p, F_IN_SHADOW, index, occluded ? 1u : 0u); haveRay = false; } // :167
+                const uint32_t my = next + prefix_rank(idleMask);
+                if (my < end) {
+                    index = qSh[my];                                         // :159
+                    haveRay = true; occluded = false;
+                    if (STATS) rays++;
+                    o = ld3(p, F_SH_OX, index); d = ld3(p, F_SH_DX, index);  // :162-163
+                    lightDistance = ldf(p, F_LIGHT_DIST, index);             // :164
+                    invdir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    stk.ptr = 0;
+                    cur = (ray_box(ts.rootMin[0], ts.rootMin[1], ts.rootMin[2], ts.rootMax[0], ts.rootMax[1], ts.rootMax[2], o, invdir) > 0.0f) ? ts.rootDesc : kDone;
+                    if (STATS) { if (cur < 0 && cur != kDone) tc.leaves++; }
+                }
+            }
+            if (nIdle == 64 && next >= end) break;
+            next = (next + (uint32_t)nIdle < end) ? next + (uint32_t)nIdle : end;
+        }
+        bool stepped = false;
+#pragma unroll
+        for (int rep = 0; rep < REPS; rep++) {
+            if (cur >= 0) {
+                if (STATS) { tc.inner++; if (prefix_rank(__ballot(1)) == 0) wIn++; }
+                cur = inner_step(ts, cur, o, invdir, stk, p.stats);
+                if (STATS) { if (cur < 0 && cur != kDone) tc.leaves++; }
+                stepped = true;
+            }
+        }
+        if (!stepped && cur != kDone) {
+            if (STATS) { tc.tris++; if (prefix_rank(__ballot(1)) == 0) wTr++; }
+            const int i = ~cur;
+            float t = 0.0f, u = 0.0f, v = 0.0f; bool last;
+            if (tri_test(ts.tris, i, o, d, t, u, v, last)) {
+                // shadowRayCast.hlsl:41-45,89: t in (1e-8, 1e8) and |d t| < lightDistance => occluded, stop
+                if (t > kEpsilon && t < 1.0f / kEpsilon && length3(d * t) < lightDistance) occluded = true;
+            }
+            cur = occluded ? kDone : (last ? stk.pop() : ~(i + 1));
+            if (STATS) { if (!occluded && last && cur < 0 && cur != kDone) tc.leaves++; }
+        }
+    }
+    if (STATS) { flush_counts(p.stats, tc, rays, false); flush_wave_iters(p.stats, wIn, wTr, false); }
+}
+
+// ------------------------------------------------------------------------------------------------ host launchers
+void launch_extend(const RenderParams& p, uint32_t blocks, bool stats, int mode, hipStream_t s)
+{
+    if (mode >= 3) {
+        const uint32_t pb = (p.L + p.raysPerWave * (kTravBlock / 64) - 1) / (p.raysPerWave * (kTravBlock / 64));
+        const int v = mode - 3;
+#define GMUPT_EXT_CASE(N, REPS, REFILL) case N: if (stats) hipLaunchKernelGGL((k_extend_i<true, REPS, REFILL>), dim3(pb), dim3(kTravBlock), 0, s, p); \
+                                                else hipLaunchKernelGGL((k_extend_i<false, REPS, REFILL>), dim3(pb), dim3(kTravBlock), 0, s, p); break;
+        switch (v) { GMUPT_EXT_CASE(0, 1, 20) GMUPT_EXT_CASE(1, 2, 20) GMUPT_EXT_CASE(2, 3, 20) GMUPT_EXT_CASE(3, 1, 8) GMUPT_EXT_CASE(4, 2, 8) GMUPT_EXT_CASE(5, 2, 12) default: break; }
+    } else if (mode == 0) {
+        const uint32_t pb = (p.L + kRaysPerWave * (kTravBlock / 64) - 1) / (kRaysPerWave * (kTravBlock / 64));
+        if (stats) hipLaunchKernelGGL(k_extend_p<true>, dim3(pb), dim3(kTravBlock), 0, s, p);
+        else hipLaunchKernelGGL(k_extend_p<false>, dim3(pb), dim3(kTravBlock), 0, s, p);
+    } else if (mode == 1) {
         if (stats) hipLaunchKernelGGL(k_extend_ref<true>, dim3(blocks), dim3(kTravBlock), 0, s, p);
         else hipLaunchKernelGGL(k_extend_ref<false>, dim3(blocks), dim3(kTravBlock), 0, s, p);
     } else {
@@ -481,9 +908,19 @@ void launch_extend(const RenderParams& p, uint32_t blocks, bool stats, bool refL
         else hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(kTravBlock), 0, s, p);
     }
 }
-void launch_shadow(const RenderParams& p, uint32_t blocks, bool stats, bool refLayout, hipStream_t s)
+void launch_shadow(const RenderParams& p, uint32_t blocks, bool stats, int mode, hipStream_t s)
 {
-    if (refLayout) {
+    if (mode >= 3) {
+        const uint32_t pb = (p.L + p.raysPerWave * (kTravBlock / 64) - 1) / (p.raysPerWave * (kTravBlock / 64));
+        const int v = mode - 3;
+#define GMUPT_SH_CASE(N, REPS, REFILL) case N: if (stats) hipLaunchKernelGGL((k_shadow_i<true, REPS, REFILL>), dim3(pb), dim3(kTravBlock), 0, s, p); \
+                                               else hipLaunchKernelGGL((k_shadow_i<false, REPS, REFILL>), dim3(pb), dim3(kTravBlock), 0, s, p); break;
+        switch (v) { GMUPT_SH_CASE(0, 1, 20) GMUPT_SH_CASE(1, 2, 20) GMUPT_SH_CASE(2, 3, 20) GMUPT_SH_CASE(3, 1, 8) GMUPT_SH_CASE(4, 2, 8) GMUPT_SH_CASE(5, 2, 12) default: break; }
+    } else if (mode == 0) {
+        const uint32_t pb = (p.L + kRaysPerWave * (kTravBlock / 64) - 1) / (kRaysPerWave * (kTravBlock / 64));
+        if (stats) hipLaunchKernelGGL(k_shadow_p<true>, dim3(pb), dim3(kTravBlock), 0, s, p);
+        else hipLaunchKernelGGL(k_shadow_p<false>, dim3(pb), dim3(kTravBlock), 0, s, p);
+    } else if (mode == 1) {
         if (stats) hipLaunchKernelGGL(k_shadow_ref<true>, dim3(blocks), dim3(kTravBlock), 0, s, p);
         else hipLaunchKernelGGL(k_shadow_ref<false>, dim3(blocks), dim3(kTravBlock), 0, s, p);
     } else {

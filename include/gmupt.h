@@ -145,6 +145,8 @@ typedef struct {
     /* device time per stage group in ms, accumulated since the last reset (HIP events on the renderer's stream; timing must be enabled) */
     double ms_logic, ms_scan, ms_accumulate, ms_material, ms_extend, ms_shadow;
     uint64_t timed_iterations;
+    /* collect_stats only: wave-level loop iterations of the ray casts; SIMD efficiency = lane steps / (64 * wave iterations) */
+    uint64_t ext_wave_inner, ext_wave_tris, sh_wave_inner, sh_wave_tris;
 } gmupt_stats;
 int gmupt_get_stats(gmupt_renderer* r, gmupt_stats* out); /* synchronises */
 int gmupt_reset_stats(gmupt_renderer* r);
