@@ -54,10 +54,10 @@ class Stats(C.Structure):
                 ("sh_rays", C.c_uint64), ("sh_inner", C.c_uint64), ("sh_leaves", C.c_uint64), ("sh_tris", C.c_uint64),
                 ("ms_logic", C.c_double), ("ms_scan", C.c_double), ("ms_accumulate", C.c_double), ("ms_material", C.c_double),
                 ("ms_extend", C.c_double), ("ms_shadow", C.c_double), ("timed_iterations", C.c_uint64),
-                ("ext_wave_inner", C.c_uint64), ("ext_wave_tris", C.c_uint64), ("sh_wave_inner", C.c_uint64), ("sh_wave_tris", C.c_uint64)]
+                ("ext_wave_inner", C.c_uint64), ("ext_wave_tris", C.c_uint64), ("sh_wave_inner", C.c_uint64), ("sh_wave_tris", C.c_uint64), ("ext_depth_hist", C.c_uint64 * 32)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        return {n: (list(getattr(self, n)) if n == "ext_depth_hist" else getattr(self, n)) for n, _ in self._fields_}
 
 
 class SbvhParams(C.Structure):

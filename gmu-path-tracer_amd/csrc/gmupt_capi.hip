@@ -161,7 +161,7 @@ struct gmupt_renderer {
     double msStage[5] = { 0, 0, 0, 0, 0 }; uint64_t timedIters = 0;
     std::vector<void*> allocs;
     // packed traversal copy of the bound scene
-    void* travNodes = nullptr; void* travTris = nullptr;
+    void* travNodes = nullptr; void* travTris = nullptr; void* travRecs = nullptr;
     int travMode = 4; // GMUPT_TRAVERSAL (A/B timing): default "ifif1" interleaved persistent lanes | "ififN" tuning variants | "whilewhile" | "static" one ray per lane | "ref" reference-layout buffers
 };
 
@@ -197,6 +197,7 @@ extern "C" void gmupt_renderer_destroy(gmupt_renderer* r)
     if (r->p.listHead) (void)hipFree(r->p.listHead);
     if (r->travNodes) (void)hipFree(r->travNodes);
     if (r->travTris) (void)hipFree(r->travTris);
+    if (r->travRecs) (void)hipFree(r->travRecs);
     if (r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
 }
@@ -209,7 +210,7 @@ extern "C" int gmupt_renderer_create(gmupt_device* dev, const gmupt_renderer_des
     gmupt_renderer* r = new (std::nothrow) gmupt_renderer();
     if (!r) return fail(GMUPT_ERR_OUT_OF_MEMORY, "gmupt_renderer_create: out of host memory");
     r->dev = dev; r->desc = *desc;
-    { const char* tv = std::getenv("GMUPT_TRAVERSAL"); r->travMode = !tv ? 4 : (std::strcmp(tv, "ref") == 0 ? 1 : (std::strcmp(tv, "static") == 0 ? 2 : (std::strncmp(tv, "ifif", 4) == 0 ? 3 + std::atoi(tv + 4) : (std::strcmp(tv, "whilewhile") == 0 ? 0 : 4)))); }
+    { const char* tv = std::getenv("GMUPT_TRAVERSAL"); r->travMode = !tv ? 4 : (std::strcmp(tv, "ref") == 0 ? 1 : (std::strcmp(tv, "static") == 0 ? 2 : (std::strncmp(tv, "ifif", 4) == 0 ? 3 + std::atoi(tv + 4) : (std::strcmp(tv, "whilewhile") == 0 ? 0 : (std::strcmp(tv, "coop") == 0 ? 20 : (std::strcmp(tv, "top") == 0 ? 30 : 4)))))); }
     if (r->desc.pool_paths == 0) r->desc.pool_paths = GMUPT_PATHCOUNT;
     if (r->desc.live_paths == 0 || r->desc.live_paths > r->desc.pool_paths) r->desc.live_paths = r->desc.pool_paths;
     const uint32_t P = r->desc.pool_paths, L = r->desc.live_paths;
@@ -275,8 +276,23 @@ static int build_traversal_copy(gmupt_renderer* r, const gmupt_buffer* nodesB, c
             if (n.left < 0 || n.right < n.left || (size_t)n.right > R) return fail(GMUPT_ERR_INVALID_ARGUMENT, "bind_scene: leaf %zu has triangle range [%d, %d) outside [0, %zu)", i, n.left, n.right, R);
         } else {
             if (n.left <= (int32_t)i || n.right <= (int32_t)i || (size_t)n.left >= N || (size_t)n.right >= N) return fail(GMUPT_ERR_INVALID_ARGUMENT, "bind_scene: inner node %zu has children (%d, %d) outside (%zu, %zu)", i, n.left, n.right, i, N);
-            innerIndex[i] = numInner++;
+            numInner++;
         }
+    }
+    // packed numbering: the first kTopTreeNodes inner nodes in breadth-first order (the part of the tree every ray walks; the
+    // ray-cast kernels keep it in LDS), then the remaining inner nodes in flatten order
+    {
+        std::vector<int32_t> bfs; bfs.reserve(kTopTreeNodes);
+        if (!nodes[0].isLeaf) bfs.push_back(0);
+        for (size_t h = 0; h < bfs.size() && bfs.size() < (size_t)kTopTreeNodes; h++) {
+            const gmupt_bvh_node& n = nodes[(size_t)bfs[h]];
+            if (!nodes[(size_t)n.left].isLeaf && bfs.size() < (size_t)kTopTreeNodes) bfs.push_back(n.left);
+            if (!nodes[(size_t)n.right].isLeaf && bfs.size() < (size_t)kTopTreeNodes) bfs.push_back(n.right);
+        }
+        int32_t nextIdx = 0;
+        for (int32_t v : bfs) innerIndex[(size_t)v] = nextIdx++;
+        for (size_t i = 0; i < N; i++) if (!nodes[i].isLeaf && innerIndex[i] < 0) innerIndex[i] = nextIdx++;
+        r->p.trav.topCount = (uint32_t)bfs.size();
     }
     for (size_t i = 0; i < R; i++)
         for (int k = 0; k < 3; k++)
@@ -288,6 +304,8 @@ static int build_traversal_copy(gmupt_renderer* r, const gmupt_buffer* nodesB, c
         // an empty leaf cannot be expressed by "first record + last flag": point it at a degenerate sentinel record
         return ~(c.right > c.left ? c.left : (int32_t)R);
     };
+    std::vector<int32_t> depth(N, 0);
+    for (size_t i = 0; i < N; i++) if (!nodes[i].isLeaf) { depth[(size_t)nodes[i].left] = depth[i] + 1; depth[(size_t)nodes[i].right] = depth[i] + 1; }
     std::vector<Node64> packed((size_t)numInner ? (size_t)numInner : 1);
     std::memset(packed.data(), 0, packed.size() * sizeof(Node64));
     for (size_t i = 0; i < N; i++) {
@@ -298,7 +316,7 @@ static int build_traversal_copy(gmupt_renderer* r, const gmupt_buffer* nodesB, c
         o.a[0] = L.min[0]; o.a[1] = L.min[1]; o.a[2] = L.min[2]; o.a[3] = L.max[0];
         o.b[0] = L.max[1]; o.b[1] = L.max[2]; o.b[2] = Rn.min[0]; o.b[3] = Rn.min[1];
         o.c[0] = Rn.min[2]; o.c[1] = Rn.max[0]; o.c[2] = Rn.max[1]; o.c[3] = Rn.max[2];
-        o.d[0] = desc(nodes[i].left); o.d[1] = desc(nodes[i].right); o.d[2] = 0; o.d[3] = 0;
+        o.d[0] = desc(nodes[i].left); o.d[1] = desc(nodes[i].right); o.d[2] = depth[i]; o.d[3] = 0;
     }
     std::vector<Tri48> ptris(R + 1);
     std::memset(ptris.data(), 0, ptris.size() * sizeof(Tri48));
@@ -320,7 +338,19 @@ static int build_traversal_copy(gmupt_renderer* r, const gmupt_buffer* nodesB, c
     HIP_TRY(hipMalloc(&r->travTris, ptris.size() * sizeof(Tri48)));
     HIP_TRY(hipMemcpy(r->travNodes, packed.data(), packed.size() * sizeof(Node64), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(r->travTris, ptris.data(), ptris.size() * sizeof(Tri48), hipMemcpyHostToDevice));
+    // unified 64-byte records for the cooperative kernels
+    std::vector<Rec64> recs(packed.size() + ptris.size());
+    std::memset(recs.data(), 0, recs.size() * sizeof(Rec64));
+    for (size_t i = 0; i < packed.size(); i++) std::memcpy(&recs[i], &packed[i], 64);
+    for (size_t i = 0; i < ptris.size(); i++) {
+        std::memcpy(&recs[packed.size() + i], &ptris[i], 48);
+        if (i < R) std::memcpy(&recs[packed.size() + i].q[12], &tris[i], 16); // (v0, v1, v2, materialID)
+    }
+    if (r->travRecs) { HIP_TRY(hipFree(r->travRecs)); r->travRecs = nullptr; }
+    HIP_TRY(hipMalloc(&r->travRecs, recs.size() * sizeof(Rec64)));
+    HIP_TRY(hipMemcpy(r->travRecs, recs.data(), recs.size() * sizeof(Rec64), hipMemcpyHostToDevice));
     TravScene& t = r->p.trav;
+    t.recs = (const Rec64*)r->travRecs; t.triBase = (uint32_t)packed.size();
     t.nodes = (const Node64*)r->travNodes; t.tris = (const Tri48*)r->travTris;
     t.rootDesc = nodes[0].isLeaf ? ~(nodes[0].right > nodes[0].left ? nodes[0].left : (int32_t)R) : innerIndex[0];
     for (int k = 0; k < 3; k++) { t.rootMin[k] = nodes[0].min[k]; t.rootMax[k] = nodes[0].max[k]; }
@@ -497,6 +527,7 @@ extern "C" int gmupt_get_stats(gmupt_renderer* r, gmupt_stats* out)
     out->ms_accumulate = 0.0; // accumulation is fused into the material kernel
     out->ms_extend = r->msStage[3]; out->ms_shadow = r->msStage[4];
     out->timed_iterations = r->timedIters;
+    for (int k = 0; k < 32; k++) out->ext_depth_hist[k] = ds.extDepthHist[k];
     out->ext_wave_inner = ds.extWaveInner; out->ext_wave_tris = ds.extWaveTris; out->sh_wave_inner = ds.shWaveInner; out->sh_wave_tris = ds.shWaveTris;
     return GMUPT_OK;
 }

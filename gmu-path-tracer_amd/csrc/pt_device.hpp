@@ -48,6 +48,7 @@ struct DevStats {
     unsigned long long extRays, extInner, extLeaves, extTris;
     unsigned long long shRays, shInner, shLeaves, shTris;
     unsigned long long extWaveInner, extWaveTris, shWaveInner, shWaveTris; // wave-level loop iterations (SIMD efficiency = lane steps / (64 * wave iterations))
+    unsigned long long extDepthHist[32]; // collect_stats: inner-node visits of the extension rays by node depth
     uint32_t activePaths;
     uint32_t stackOverflow; // traversal needed more than the provisioned stack (results then differ from an unbounded stack)
 };
@@ -76,10 +77,20 @@ struct alignas(64) Node64 { float a[4], b[4], c[4]; int32_t d[4]; };
 struct alignas(16) Tri48 { float r0[4], r1[4], r2[4]; };
 static_assert(sizeof(Node64) == 64 && sizeof(Tri48) == 48, "packed traversal records");
 
+// Rec64: the same data as 64-byte records in ONE array (inner nodes first, then one record per triangle reference) for the
+// cooperative ray-cast kernels: a lane needs exactly one record per step, and four adjacent lanes fetch the four 16-byte
+// quarters of one record with a single LDS-DMA instruction.  Triangle record: r0..r2 as Tri48, r3 = (v0, v1, v2, materialID).
+struct alignas(64) Rec64 { float q[16]; };
+
+constexpr int kTopTreeNodes = 256; // inner nodes (breadth-first from the root) that the ray-cast kernels keep in LDS: 16 KB
+
 struct TravScene {
+    const Rec64* recs;
+    uint32_t triBase;      // index of the first triangle record in recs (= number of inner nodes)
     const Node64* nodes;
     const Tri48* tris;
     int32_t rootDesc;
+    uint32_t topCount;     // nodes[0 .. topCount) are the breadth-first top of the tree
     float rootMin[3], rootMax[3];
 };
 

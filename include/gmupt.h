@@ -147,6 +147,7 @@ typedef struct {
     uint64_t timed_iterations;
     /* collect_stats only: wave-level loop iterations of the ray casts; SIMD efficiency = lane steps / (64 * wave iterations) */
     uint64_t ext_wave_inner, ext_wave_tris, sh_wave_inner, sh_wave_tris;
+    uint64_t ext_depth_hist[32]; /* inner-node visits of the extension rays by node depth */
 } gmupt_stats;
 int gmupt_get_stats(gmupt_renderer* r, gmupt_stats* out); /* synchronises */
 int gmupt_reset_stats(gmupt_renderer* r);

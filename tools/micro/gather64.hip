@@ -1,0 +1,75 @@
+// Micro-benchmark: throughput of random 64-byte record gathers on MI355X, per access shape.
+//  A: one lane fetches its whole record (4 x global_load_dwordx4 at 4 consecutive 16-B offsets)          -> 64 records / 4 instr
+//  B: the 4 lanes of a quad fetch the 4 quarters of one record (1 x dwordx4 per lane and record)        -> 16 records / instr
+//  C: as A but every lane of a quad reads the SAME record (coherent rays)                                -> 16 distinct records / 4 instr
+//  D: one lane fetches a 48-byte record (3 x dwordx4)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k(const float4* __restrict__ recs, const unsigned* __restrict__ idx, float* out, int iters, unsigned n)
+{
+    const unsigned gtid = blockIdx.x * 256 + threadIdx.x;
+    const unsigned lane = threadIdx.x & 63;
+    float acc = 0.f;
+    unsigned r = idx[gtid % n];
+    for (int it = 0; it < iters; it++) {
+        if (MODE == 0) {
+            const float4* p = recs + 4ull * r;
+            float4 a = p[0], b = p[1], c = p[2], d = p[3];
+            acc += a.x + b.y + c.z + d.w;
+            r = (__float_as_uint(d.x) + r * 1664525u + it) % n; // dependent chain like a traversal
+        } else if (MODE == 1) {
+            unsigned r0 = __shfl(r, (lane & ~3u) + 0), r1 = __shfl(r, (lane & ~3u) + 1), r2 = __shfl(r, (lane & ~3u) + 2), r3 = __shfl(r, (lane & ~3u) + 3);
+            const unsigned q = lane & 3;
+            float4 a = recs[4ull * r0 + q], b = recs[4ull * r1 + q], c = recs[4ull * r2 + q], d = recs[4ull * r3 + q];
+            acc += a.x + b.y + c.z + d.w;
+            float mine = (q == 0) ? a.x : (q == 1) ? b.x : (q == 2) ? c.x : d.x;
+            r = (__float_as_uint(mine) + r * 1664525u + it) % n;
+        } else if (MODE == 2) {
+            unsigned rq = __shfl(r, lane & ~3u);
+            const float4* p = recs + 4ull * rq;
+            float4 a = p[0], b = p[1], c = p[2], d = p[3];
+            acc += a.x + b.y + c.z + d.w;
+            r = (__float_as_uint(d.x) + r * 1664525u + it) % n;
+        } else {
+            const float4* p = recs + 3ull * r;
+            float4 a = p[0], b = p[1], c = p[2];
+            acc += a.x + b.y + c.z;
+            r = (__float_as_uint(c.x) + r * 1664525u + it) % n;
+        }
+    }
+    out[gtid] = acc;
+}
+
+int main(int argc, char** argv)
+{
+    const unsigned n = argc > 1 ? atoi(argv[1]) : 400000;   // records (x64 B)
+    const int iters = 64, blocks = 256 * 8, threads = blocks * 256;
+    std::vector<float> h((size_t)n * 16);
+    for (size_t i = 0; i < h.size(); i++) h[i] = (float)(rand() % 1000000);
+    std::vector<unsigned> hi(threads);
+    for (auto& v : hi) v = rand() % n;
+    float4* recs; unsigned* idx; float* out;
+    CHECK(hipMalloc(&recs, h.size() * 4)); CHECK(hipMalloc(&idx, hi.size() * 4)); CHECK(hipMalloc(&out, threads * 4));
+    CHECK(hipMemcpy(recs, h.data(), h.size() * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(idx, hi.data(), hi.size() * 4, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const char* names[4] = { "A lane=record 4x16B", "B quad=record 1x16B x4 recs", "C quad shares record", "D lane=48B record" };
+    for (int rep = 0; rep < 2; rep++)
+        for (int m = 0; m < 4; m++) {
+            CHECK(hipEventRecord(e0));
+            if (m == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, recs, idx, out, iters, n);
+            if (m == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, recs, idx, out, iters, n);
+            if (m == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, recs, idx, out, iters, n);
+            if (m == 3) hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), 0, 0, recs, idx, out, iters, n / 4 * 4 / 3);
+            CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            const double recsFetched = (double)threads * iters;
+            if (rep) printf("%-30s %8.3f ms  %7.1f Grec/s  %7.1f GB/s useful  (%.2f cycles/lane-record/CU)\n", names[m], ms, recsFetched / ms / 1e6,
+                            recsFetched * (m == 3 ? 48 : 64) / ms / 1e6, ms * 1e-3 * 2.4e9 * 256 / recsFetched);
+        }
+    return 0;
+}
