@@ -8,6 +8,10 @@ Source/Renderer.cpp:195-211).  Workload (BASELINE.json configs[2]): the seeded ~
 PBR + glass + NEE shadow rays, unbounded depth, pool of 2^21 paths per GPU; inputs (scene, path pool) are resident in HBM
 before the timed region.  Before the W warm-up steps the pool is pre-warmed to its steady state (paths of all ages in
 flight, as during a 64-spp render); the value is completed camera paths per second over the K timed steps.
+Steady state needs care: the reference has no depth limit and kills paths by Russian roulette only after 200 bounces
+(logic.hlsl:248-255), so in this closed room ~55 % of the paths end at length 201 and a pool that starts in lock-step
+completes paths in bursts with a period of 201 iterations (damping 0.55 per period).  The default pre-warm is ten periods
+(2010 iterations, ~4 s) and the default K is one period (201), which makes the value independent of the phase.
 With N GPUs the frame is split into N row bands (one private pipeline per rank, no data-path collective); the timed region
 ends with the RCCL gather of the tiles to rank 0.
 
@@ -36,9 +40,9 @@ def ext_bytes(rays, inner, tris, lights):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=201)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--prewarm", type=int, default=260, help="untimed iterations that bring the pool to steady state")
+    ap.add_argument("--prewarm", type=int, default=2010, help="untimed iterations that bring the pool to its steady state (see the module docstring)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64, help="named in the config; the steady-state rate does not depend on it")
@@ -47,8 +51,10 @@ def main():
     ap.add_argument("--subdiv", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the counting replay that measures I and T")
+    ap.add_argument("--no-stage-timing", action="store_true", help="do not record per-stage HIP events in the timed region")
     ap.add_argument("--cpu-pool", type=int, default=1 << 15)
-    ap.add_argument("--cpu-iters", type=int, default=40)
+    ap.add_argument("--cpu-iters", type=int, default=201)
+    ap.add_argument("--cpu-prewarm", type=int, default=402)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -104,7 +110,7 @@ def main():
     step(r, cam, args.prewarm + args.warmup)
     r.synchronize()
     r.reset_stats()
-    r.enable_timing(True)
+    r.enable_timing(not args.no_stage_timing)
     tile_t = torch.empty((rows, W, 4), dtype=torch.float32, device="cuda")
 
     barrier()
@@ -186,7 +192,7 @@ def main():
 def run_cpu_baseline(scene, W, H, args):
     """The scalar CPU oracle (oracle/, a port of the same six stages) on a bounded sample of the same workload."""
     import oracle_lib as O
-    threads = os.cpu_count() or 1
+    threads = min(os.cpu_count() or 1, 16)   # the box's CPU share for one GPU
     pool = args.cpu_pool
     orc = O.Renderer(scene, W, H, pool, threads=threads)
     cam = O.Camera(W, H)
@@ -197,7 +203,7 @@ def run_cpu_baseline(scene, W, H, args):
         for _ in range(n):
             cam.update(); orc.set_camera(cam.buffer); orc.iterate()
     t0 = time.perf_counter()
-    step(230)  # bring the (small) pool to the same steady state
+    step(args.cpu_prewarm)   # periods of the 201-iteration completion cycle (see the module docstring)
     orc.reset_stats()
     t1 = time.perf_counter()
     step(args.cpu_iters)
@@ -205,8 +211,8 @@ def run_cpu_baseline(scene, W, H, args):
     s = orc.stats()
     orc.close()
     return {"value": round(s.pathsEnded / dt / 1e6, 5), "unit": "Mpaths/s", "cores": threads, "kind": "port",
-            "sample": "oracle, pool %d, %d steady-state iterations (%.1f s, after %.1f s pre-warm), same scene/resolution; ray casts on %d OpenMP threads, shading stages serial"
-                      % (pool, args.cpu_iters, dt, t1 - t0, threads),
+            "sample": "oracle (scalar C port of the six stages), pool %d, %d timed iterations = one completion period (%.1f s) after %d pre-warm iterations (%.1f s), same scene / resolution / camera; ray casts on %d OpenMP threads, shading stages serial"
+                      % (pool, args.cpu_iters, dt, args.cpu_prewarm, t1 - t0, threads),
             "msegments_per_s": round(s.segments / dt / 1e6, 3)}
 
 

@@ -36,6 +36,7 @@ void launch_extend(const RenderParams& p, uint32_t blocks, bool stats, int mode,
 void launch_shadow(const RenderParams& p, uint32_t blocks, bool stats, int mode, hipStream_t s);
 void launch_detmath(int fn, const float* x, const float* y, float* out, uint32_t n, hipStream_t s);
 uint32_t traversal_block_threads();
+uint32_t deferred_block_threads();
 uint32_t traversal_overflow_entries();
 }
 using namespace gmupt;
@@ -162,7 +163,7 @@ struct gmupt_renderer {
     std::vector<void*> allocs;
     // packed traversal copy of the bound scene
     void* travNodes = nullptr; void* travTris = nullptr; void* travRecs = nullptr;
-    int travMode = 4; // GMUPT_TRAVERSAL (A/B timing): default "ifif1" interleaved persistent lanes | "ififN" tuning variants | "whilewhile" | "static" one ray per lane | "ref" reference-layout buffers
+    int travMode = 40; // GMUPT_TRAVERSAL (A/B timing): default "def0" deferred-leaf kernels with the top of the tree in LDS | "defN" variants | "ififN" interleaved | "whilewhile" | "static" | "top" | "coop" | "ref" reference-layout buffers
 };
 
 static int dev_alloc(gmupt_renderer* r, void** ptr, size_t bytes, int fill)
@@ -210,7 +211,7 @@ extern "C" int gmupt_renderer_create(gmupt_device* dev, const gmupt_renderer_des
     gmupt_renderer* r = new (std::nothrow) gmupt_renderer();
     if (!r) return fail(GMUPT_ERR_OUT_OF_MEMORY, "gmupt_renderer_create: out of host memory");
     r->dev = dev; r->desc = *desc;
-    { const char* tv = std::getenv("GMUPT_TRAVERSAL"); r->travMode = !tv ? 4 : (std::strcmp(tv, "ref") == 0 ? 1 : (std::strcmp(tv, "static") == 0 ? 2 : (std::strncmp(tv, "ifif", 4) == 0 ? 3 + std::atoi(tv + 4) : (std::strcmp(tv, "whilewhile") == 0 ? 0 : (std::strcmp(tv, "coop") == 0 ? 20 : (std::strcmp(tv, "top") == 0 ? 30 : 4)))))); }
+    { const char* tv = std::getenv("GMUPT_TRAVERSAL"); r->travMode = !tv ? 40 : (std::strcmp(tv, "ref") == 0 ? 1 : (std::strcmp(tv, "static") == 0 ? 2 : (std::strncmp(tv, "ifif", 4) == 0 ? 3 + std::atoi(tv + 4) : (std::strcmp(tv, "whilewhile") == 0 ? 0 : (std::strcmp(tv, "coop") == 0 ? 20 : (std::strcmp(tv, "top") == 0 ? 30 : (std::strncmp(tv, "def", 3) == 0 ? 40 + std::atoi(tv + 3) : 40))))))); }
     if (r->desc.pool_paths == 0) r->desc.pool_paths = GMUPT_PATHCOUNT;
     if (r->desc.live_paths == 0 || r->desc.live_paths > r->desc.pool_paths) r->desc.live_paths = r->desc.pool_paths;
     const uint32_t P = r->desc.pool_paths, L = r->desc.live_paths;
@@ -228,7 +229,10 @@ extern "C" int gmupt_renderer_create(gmupt_device* dev, const gmupt_renderer_des
     const uint32_t tb = traversal_block_threads();
     r->travBlocks = (L + tb - 1) / tb;
     p.ovfStride = r->travBlocks * tb;
-    { const char* rw = std::getenv("GMUPT_RAYS_PER_WAVE"); p.raysPerWave = rw ? (uint32_t)std::atoi(rw) : 512u; if (p.raysPerWave < 64) p.raysPerWave = 64; }
+    if (p.ovfStride < deferred_block_threads()) p.ovfStride = deferred_block_threads();
+    { const char* rw = std::getenv("GMUPT_RAYS_PER_WAVE"); p.raysPerWave = rw ? (uint32_t)std::atoi(rw) : 128u; if (p.raysPerWave < 64) p.raysPerWave = 64; }
+    { const char* wpc = std::getenv("GMUPT_WAVES_PER_CU"); const uint32_t w = wpc ? (uint32_t)std::atoi(wpc) : 16u; const uint32_t db = deferred_block_threads(); p.travGridBlocks = (uint32_t)dev->prop.multiProcessorCount * ((w * 64 + db - 1) / db); if (p.travGridBlocks * db > p.ovfStride) p.travGridBlocks = p.ovfStride / db; if (p.travGridBlocks == 0) p.travGridBlocks = 1; }
+    { const char* e1 = std::getenv("GMUPT_REFILL"); p.tuneRefill = e1 ? (uint32_t)std::atoi(e1) : 20u; const char* e2 = std::getenv("GMUPT_TRI_THRESH"); p.tuneTriThresh = e2 ? (uint32_t)std::atoi(e2) : 32u; }
 
     int rc = GMUPT_OK;
     // Renderer::createBuffers creates the UAV buffers without initial data: D3D11 zero-initialises them
@@ -241,6 +245,7 @@ extern "C" int gmupt_renderer_create(gmupt_device* dev, const gmupt_renderer_des
     if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.queues, (size_t)P * 20, 0);
     if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.qc, 32, 0);
     if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.stats, sizeof(DevStats), 0);
+    if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.travCounters, 16, 0);
     if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.ovfStack, (size_t)p.ovfStride * traversal_overflow_entries() * 4, 0);
     if (rc == GMUPT_OK) rc = alloc_framebuffer(r, desc->width, desc->height);
     if (rc == GMUPT_OK) {
@@ -351,6 +356,7 @@ static int build_traversal_copy(gmupt_renderer* r, const gmupt_buffer* nodesB, c
     HIP_TRY(hipMemcpy(r->travRecs, recs.data(), recs.size() * sizeof(Rec64), hipMemcpyHostToDevice));
     TravScene& t = r->p.trav;
     t.recs = (const Rec64*)r->travRecs; t.triBase = (uint32_t)packed.size();
+    { int32_t md = 0; for (size_t i = 0; i < N; i++) md = std::max(md, depth[i]); t.maxDepth = (uint32_t)md; }
     t.nodes = (const Node64*)r->travNodes; t.tris = (const Tri48*)r->travTris;
     t.rootDesc = nodes[0].isLeaf ? ~(nodes[0].right > nodes[0].left ? nodes[0].left : (int32_t)R) : innerIndex[0];
     for (int k = 0; k < 3; k++) { t.rootMin[k] = nodes[0].min[k]; t.rootMax[k] = nodes[0].max[k]; }

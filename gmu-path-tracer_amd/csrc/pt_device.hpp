@@ -91,6 +91,7 @@ struct TravScene {
     const Tri48* tris;
     int32_t rootDesc;
     uint32_t topCount;     // nodes[0 .. topCount) are the breadth-first top of the tree
+    uint32_t maxDepth;     // depth of the deepest node (bounds the traversal stack)
     float rootMin[3], rootMax[3];
 };
 
@@ -114,6 +115,9 @@ struct RenderParams {
     int* ovfStack;         // global overflow of the traversal stacks
     uint32_t ovfStride;    // threads of the traversal grid
     uint32_t raysPerWave;  // queue entries owned by one wave of the persistent ray-cast kernels
+    uint32_t* travCounters; // [0] extension, [1] shadow: next unassigned queue entry (zeroed by k_scan every iteration)
+    uint32_t travGridBlocks; // persistent ray-cast grid
+    uint32_t tuneRefill, tuneTriThresh; // lane-refill / triangle-burst thresholds of the deferred-leaf kernels
     gmupt_camera_buffer cam;
     SceneView scene;
     TravScene trav;

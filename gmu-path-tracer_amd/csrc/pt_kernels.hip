@@ -226,6 +226,7 @@ __global__ __launch_bounds__(1024) void k_scan(RenderParams p, int clearFrame)
         p.qc[QC_EXT_GLASS_OFFSET] = qc0 + nUE4;                     // newPath.hlsl:58
         p.qc[QC_SHADOWRAY] = s_total[3];                           // newPath.hlsl:59 resets it, materialUE4.hlsl:173 counts it up to this total
         p.qc[QC_EXT_COUNT] = nNew + nUE4 + nGlass;
+        p.travCounters[0] = 0; p.travCounters[1] = 0;
         uint32_t gen = nNew;
         if (p.budget) { uint32_t remaining = p.budget > lastPath ? p.budget - lastPath : 0u; if (gen > remaining) gen = remaining; }
         DevStats* st = p.stats;

