@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--pool", type=int, default=1 << 21)
     ap.add_argument("--spheres", type=int, default=202)
     ap.add_argument("--subdiv", type=int, default=3)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL over xGMI) or gloo (rehearsal of N > 1 on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the counting replay that measures I and T")
     ap.add_argument("--no-stage-timing", action="store_true", help="do not record per-stage HIP events in the timed region")
@@ -67,10 +68,16 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev      # one rank per GPU; the modulo only matters for the gloo rehearsal on a single GPU
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
+    coll_dev = "cuda" if (world == 1 or args.backend == "nccl") else "cpu"
 
     import numpy as np
     import gmupt_pkg
@@ -84,7 +91,7 @@ def main():
     bands = tiles.row_bands(H, world)
     y0, rows = bands[rank]
 
-    dev = capi.Device(local_rank)
+    dev = capi.Device(dev_index)
     sb = capi.SceneBuffers(dev, scene)
 
     def make_renderer(stats):
@@ -117,14 +124,14 @@ def main():
     t_start = time.perf_counter()
     step(r, cam, args.steps)
     r.copy_framebuffer_to_device(tile_t.data_ptr(), tile_t.numel() * 4)  # synchronises the renderer's stream
-    frame = tiles.gather_tiles(tile_t, W, H, rank, world, dist if world > 1 else None)
+    frame = tiles.gather_tiles(tile_t if coll_dev == "cuda" else tile_t.cpu(), W, H, rank, world, dist if world > 1 else None)
     barrier()
     elapsed = time.perf_counter() - t_start
 
     st = r.stats()
     r.enable_timing(False)
-    completed = torch.tensor([float(st.paths_completed), float(st.segments)], dtype=torch.float64, device="cuda")
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    completed = torch.tensor([float(st.paths_completed), float(st.segments)], dtype=torch.float64, device=coll_dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(completed, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

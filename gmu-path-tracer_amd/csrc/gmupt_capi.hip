@@ -431,6 +431,7 @@ static int run_iteration(gmupt_renderer* r, bool doShade, bool doExtend, bool do
         launch_material(p, clearFrame, r->stream);
         if (ev) HIP_TRY(hipEventRecord(ev->e[3], r->stream));
     }
+    if (!doShade) HIP_TRY(hipMemsetAsync(p.travCounters, 0, 16, r->stream)); // k_scan zeroes the ray-cast work counters in a full iteration
     if (doExtend) { launch_extend(p, r->travBlocks, stats, r->travMode, r->stream); if (ev) HIP_TRY(hipEventRecord(ev->e[4], r->stream)); }
     if (doShadow) { launch_shadow(p, r->travBlocks, stats, r->travMode, r->stream); if (ev) HIP_TRY(hipEventRecord(ev->e[5], r->stream)); }
     HIP_TRY(hipGetLastError());

@@ -79,6 +79,9 @@ def lib():
         L.orc_camera_update.restype = None; L.orc_camera_update.argtypes = [C.POINTER(OrcCamera)]
         L.orc_msvc_rand.restype = C.c_int; L.orc_msvc_rand.argtypes = [C.POINTER(C.c_uint32)]
         L.orc_detmath_eval.restype = None; L.orc_detmath_eval.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.orc_sbvh_build.restype = C.c_int
+        L.orc_sbvh_build.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+        L.orc_sbvh_free.restype = None; L.orc_sbvh_free.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -185,3 +188,16 @@ def state_field(raw, pool, name, live=None):
     words = np.frombuffer(raw, dtype=np.uint32)
     base = off * pool // 4
     return words[base: base + (slot // 4) * pool].reshape(pool, slot // 4)[:n, :comps]
+
+
+def sbvh_build(verts, indices, vertex_material=None):
+    """The oracle's restatement of the reference SBVH build + flatten: (nodes, tris) as raw 48-byte / 16-byte records."""
+    verts = np.ascontiguousarray(verts, np.float32); indices = np.ascontiguousarray(indices, np.int32)
+    vm = None if vertex_material is None else np.ascontiguousarray(vertex_material, np.uint32)
+    pn, pt, nref = C.c_void_p(), C.c_void_p(), C.c_int(0)
+    n = lib().orc_sbvh_build(verts.ctypes.data, verts.shape[0], indices.ctypes.data, indices.shape[0],
+                             vm.ctypes.data if vm is not None else None, C.byref(pn), C.byref(pt), C.byref(nref))
+    nodes = np.frombuffer(C.string_at(pn, n * 48), dtype=np.uint8).copy()
+    tris = np.frombuffer(C.string_at(pt, nref.value * 16), dtype=np.uint8).copy()
+    lib().orc_sbvh_free(pn); lib().orc_sbvh_free(pt)
+    return nodes, tris, n, nref.value
