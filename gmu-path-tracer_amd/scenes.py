@@ -131,7 +131,7 @@ def spheres_mesh(n_spheres=202, subdiv=3, seed=1234, floor_quads=20, half_extent
         for j in range(fq):
             mb.quad((xs[i], 0.0, xs[j + 1]), (xs[i + 1], 0.0, xs[j + 1]), (xs[i + 1], 0.0, xs[j]), (xs[i], 0.0, xs[j]), (0, 1, 0), 0)
     sv, sf = icosphere(subdiv)
-    g = int(np.ceil(np.sqrt(n_spheres)))
+    g = max(1, int(np.ceil(np.sqrt(n_spheres))))
     cell = 2.0 * (E - 1.0) / g
     cells = rng.permutation(g * g)[:n_spheres]
     for k, cidx in enumerate(cells):
