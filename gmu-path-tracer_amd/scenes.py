@@ -175,6 +175,27 @@ def random_triangles_mesh(n=2000, seed=1, extent=10.0, size=1.0):
             "light_count": 2, "camera": (0.0, 2.0, 24.0, 0.0, 270.0), "name": "soup%d" % n}
 
 
+def deep_chain_mesh(n=100, factor=0.6, per=2, seed=0):
+    """Geometrically shrinking triangle clusters nested towards a corner: an unbalanced SAH tree of depth ~30, used to exercise
+    traversal stacks deeper than the LDS portion (the reference's 16-entry stack would overflow here, quirk Q23)."""
+    rng = np.random.default_rng(seed)
+    v = []
+    for k in range(n):
+        s = factor ** k * 10.0
+        c = np.array([s, s * 0.5, s * 0.3])
+        for _ in range(per):
+            v.append(c + rng.uniform(-0.2, 0.2, (3, 3)) * s)
+    v = np.concatenate(v).astype(np.float32)
+    t = np.arange(len(v), dtype=np.int32).reshape(-1, 3)
+    e1 = v[t[:, 1]] - v[t[:, 0]]; e2 = v[t[:, 2]] - v[t[:, 0]]
+    fn = np.cross(e1, e2); fn /= np.maximum(np.linalg.norm(fn, axis=1, keepdims=True), 1e-30)
+    mats = np.stack([_material((0.8, 0.8, 0.8)), _material((0.9, 0.7, 0.3), 1.0, 0.2)])
+    vm = np.repeat((np.arange(len(t)) % 2).astype(np.uint32), 3)
+    return {"verts": v, "normals": np.repeat(fn, 3, axis=0).astype(np.float32), "vertex_material": vm, "indices": t, "materials": mats,
+            "lights": _lights([(4.0, 6.0, 4.0, 100.0, 80.0, 80.0, 40.0, 0.5), (-2.0, 3.0, 5.0, 100.0, 40.0, 80.0, 80.0, 0.5)]),
+            "light_count": 2, "camera": (0.0, 0.0, 0.0, 25.6, 16.7), "name": "chain%d" % n}  # at the apex, looking along the chain
+
+
 def build_scene(mesh, sbvh_params=None):
     """BVHWrapper::buildSBVH: host SBVH build + flatten -> the buffers Renderer::draw binds (t0-t4, b1)."""
     built = capi.sbvh_build(mesh["verts"], mesh["indices"], mesh["vertex_material"], sbvh_params)

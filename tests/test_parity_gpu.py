@@ -71,6 +71,20 @@ def test_iteration_parity(pkg, device, cornell_scene, soup_scene, spheres_small_
     hip.close(); sb.close(); orc.close()
 
 
+def test_deep_tree_uses_stack_overflow_path(pkg, device):
+    # tree depth ~30: deeper than the LDS part of the traversal stacks (and than the reference's unchecked 16 entries, Q23)
+    scene = pkg.scenes.build_scene(pkg.scenes.deep_chain_mesh())
+    assert scene["depth"] > 24
+    W, H, P = 48, 32, 2048
+    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, scene, W, H, P)
+    for it in range(12):
+        PU.step_both(orc, hip, ocam, hcam)
+        _assert_same(orc, hip, P, P, it)
+    assert orc.stats().maxStack > 24, "rays along the chain must stack more deferred nodes than the LDS part of the stack holds"
+    assert hip.stats().reserved_ == 0
+    hip.close(); sb.close(); orc.close()
+
+
 def test_traversal_statistics_match(pkg, device, soup_scene):
     # the counting variant of the ray-cast kernels reports the same inner-node / triangle-test totals as the oracle for the
     # extension stage (the visited set does not depend on the traversal order)
