@@ -15,7 +15,7 @@ PATHCOUNT = 1 << 21
 REF_GRID_THREADS = 34 * 8 * 256
 STATE_BYTES = 248
 
-(BUFFER_BVH_NODES, BUFFER_TRIANGLES, BUFFER_VERTICES, BUFFER_LIGHTS, BUFFER_TRI_PROPS, BUFFER_MATERIALS) = range(6)
+(BUFFER_BVH_NODES, BUFFER_TRIANGLES, BUFFER_VERTICES, BUFFER_LIGHTS, BUFFER_TRI_PROPS, BUFFER_MATERIALS, BUFFER_TEXTURE_ARRAY) = range(7)
 STAGE_SHADE, STAGE_EXTEND, STAGE_SHADOW = range(3)
 MATERIAL_UE4, MATERIAL_GLASS = 0, 1
 
@@ -80,9 +80,11 @@ SYMBOLS = {
     "gmupt_buffer_update": (C.c_int, [_P, _P, C.c_size_t]),
     "gmupt_buffer_destroy": (None, [_P]),
     "gmupt_buffer_size": (C.c_size_t, [_P]),
+    "gmupt_texture_array_create": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     "gmupt_renderer_create": (C.c_int, [_P, C.POINTER(RendererDesc), C.POINTER(_P)]),
     "gmupt_renderer_destroy": (None, [_P]),
     "gmupt_renderer_bind_scene": (C.c_int, [_P] * 7),
+    "gmupt_renderer_bind_textures": (C.c_int, [_P, _P, _P, _P]),
     "gmupt_set_camera": (C.c_int, [_P, C.POINTER(CameraBuffer)]),
     "gmupt_iterate": (C.c_int, [_P]),
     "gmupt_resize": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
@@ -183,6 +185,21 @@ class Buffer:
             self.h = _P()
 
 
+class TextureArray:
+    """R8G8B8A8_UNORM Texture2DArray: (layers, size, size, 4) uint8."""
+
+    def __init__(self, dev, array):
+        array = np.ascontiguousarray(array, dtype=np.uint8)
+        assert array.ndim == 4 and array.shape[1] == array.shape[2] and array.shape[3] == 4
+        self.h = _P()
+        _check(lib().gmupt_texture_array_create(dev.h, _ptr(array), array.shape[1], array.shape[0], C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().gmupt_buffer_destroy(self.h)
+            self.h = _P()
+
+
 class SceneBuffers:
     """The six scene resources of Renderer::draw (t0-t4, b1) uploaded through gmupt_buffer_create."""
 
@@ -193,6 +210,8 @@ class SceneBuffers:
         self.lights = Buffer(dev, BUFFER_LIGHTS, scene["lights"])
         self.props = Buffer(dev, BUFFER_TRI_PROPS, scene["props"])
         self.materials = Buffer(dev, BUFFER_MATERIALS, scene["materials"])
+        self.textures = [TextureArray(dev, scene[k]) if scene.get(k) is not None else None
+                         for k in ("tex_diffuse", "tex_metallic_roughness", "tex_normal")]
 
     def all(self):
         return [self.nodes, self.tris, self.verts, self.lights, self.props, self.materials]
@@ -200,6 +219,9 @@ class SceneBuffers:
     def close(self):
         for b in self.all():
             b.close()
+        for t in self.textures:
+            if t is not None:
+                t.close()
 
 
 class Camera:
@@ -249,6 +271,7 @@ class Renderer:
     def bind_scene(self, sb):
         self._scene = sb  # keep the buffers alive
         _check(lib().gmupt_renderer_bind_scene(self.h, *[b.h for b in sb.all()]))
+        _check(lib().gmupt_renderer_bind_textures(self.h, *[(t.h if t is not None else None) for t in sb.textures]))
 
     def set_camera(self, cam_buffer):
         _check(lib().gmupt_set_camera(self.h, C.byref(cam_buffer)))

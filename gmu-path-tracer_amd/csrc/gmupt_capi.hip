@@ -87,13 +87,14 @@ extern "C" int gmupt_device_create(int hip_device, gmupt_device** out)
 extern "C" void gmupt_device_destroy(gmupt_device* dev) { delete dev; }
 
 // ------------------------------------------------------------------------------------------------ buffers
-struct gmupt_buffer { gmupt_device* dev; gmupt_buffer_kind kind; void* dptr; size_t bytes; size_t elems; };
+struct gmupt_buffer { gmupt_device* dev; gmupt_buffer_kind kind; void* dptr; size_t bytes; size_t elems; uint32_t texSize = 0, texLayers = 0; };
 
 static size_t kind_stride(gmupt_buffer_kind k)
 {
     switch (k) {
     case GMUPT_BUFFER_BVH_NODES: return 48; case GMUPT_BUFFER_TRIANGLES: return 16; case GMUPT_BUFFER_VERTICES: return 12;
     case GMUPT_BUFFER_LIGHTS: return 32; case GMUPT_BUFFER_TRI_PROPS: return 32; case GMUPT_BUFFER_MATERIALS: return 48;
+    case GMUPT_BUFFER_TEXTURE_ARRAY: return 4;
     }
     return 0;
 }
@@ -123,6 +124,15 @@ extern "C" int gmupt_buffer_create(gmupt_device* dev, gmupt_buffer_kind kind, co
     if (e != hipSuccess) { if (b->dptr) (void)hipFree(b->dptr); delete b; return fail(GMUPT_ERR_HIP, "gmupt_buffer_create(%zu bytes): %s", alloc, hipGetErrorString(e)); }
     *out = b;
     return GMUPT_OK;
+}
+
+extern "C" int gmupt_texture_array_create(gmupt_device* dev, const uint8_t* rgba8, uint32_t size, uint32_t layers, gmupt_buffer** out)
+{
+    if (!dev || !out || !rgba8) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_texture_array_create: null argument");
+    if (size == 0 || layers == 0 || size > 16384) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_texture_array_create: %u layers of %ux%u", layers, size, size);
+    int rc = gmupt_buffer_create(dev, GMUPT_BUFFER_TEXTURE_ARRAY, rgba8, (size_t)size * size * layers * 4, out);
+    if (rc == GMUPT_OK) { (*out)->texSize = size; (*out)->texLayers = layers; }
+    return rc;
 }
 
 extern "C" int gmupt_buffer_update(gmupt_buffer* buf, const void* data, size_t bytes)
@@ -379,6 +389,19 @@ extern "C" int gmupt_renderer_bind_scene(gmupt_renderer* r, const gmupt_buffer* 
     int rc = build_traversal_copy(r, nodes, triangles, vertices);
     if (rc != GMUPT_OK) return rc;
     r->sceneBound = true;
+    return GMUPT_OK;
+}
+
+extern "C" int gmupt_renderer_bind_textures(gmupt_renderer* r, const gmupt_buffer* diffuse, const gmupt_buffer* metallic_roughness, const gmupt_buffer* normals)
+{
+    if (!r) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_renderer_bind_textures: null renderer");
+    const gmupt_buffer* t[3] = { diffuse, metallic_roughness, normals };
+    for (int k = 0; k < 3; k++) {
+        if (t[k] && t[k]->kind != GMUPT_BUFFER_TEXTURE_ARRAY) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_renderer_bind_textures: slot %d is not a texture array", k);
+        r->p.scene.tex[k] = t[k] ? (const uint8_t*)t[k]->dptr : nullptr;
+        r->p.scene.texSize[k] = t[k] ? t[k]->texSize : 0u;
+        r->p.scene.texLayers[k] = t[k] ? t[k]->texLayers : 0u;
+    }
     return GMUPT_OK;
 }
 

@@ -64,6 +64,8 @@ struct SceneView {
     const gmupt_tri_props* props;
     const gmupt_material* materials;
     uint32_t numNodes, numTris, numVerts, numMaterials;
+    const uint8_t* tex[3];   // diffuse, metallicRoughness, normals: RGBA8 arrays of square layers (nullptr = unbound)
+    uint32_t texSize[3], texLayers[3];
 };
 
 // Packed traversal copy of the scene, built at bind time (gmupt_renderer_bind_scene) from the reference-layout buffers.

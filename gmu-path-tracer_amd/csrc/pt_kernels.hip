@@ -57,6 +57,34 @@ __device__ __forceinline__ float powerHeuristic(float rayPdf, float lightPdf) //
     return t / (lightPdf * lightPdf + t);
 }
 
+// ------------------------------------------------------------------------------------------------ textures
+// SampleLevel(linear, wrap) on an RGBA8 UNORM array (logic.hlsl:100,104,111; sampler Scene.cpp:180-192): texel centres at
+// u*size - 0.5, fp32 weights, lerp(a,b,t) = a + t*(b-a), horizontal pairs first, c/255 decode.  Stated arithmetic.
+__device__ __forceinline__ float4 sample_bilinear(const SceneView& sc, int which, float u, float v, int layer)
+{
+    float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const uint8_t* tex = sc.tex[which];
+    const int n = (int)sc.texSize[which];
+    if (!tex || n <= 0 || sc.texLayers[which] == 0) return out;
+    if (layer < 0) layer = 0;
+    if (layer >= (int)sc.texLayers[which]) layer = (int)sc.texLayers[which] - 1;
+    float x = u * (float)n - 0.5f, y = v * (float)n - 0.5f;
+    if (!(dabs(x) < 1.0e9f)) x = 0.0f;
+    if (!(dabs(y) < 1.0e9f)) y = 0.0f;
+    const float x0 = dfloor(x), y0 = dfloor(y);
+    const float fx = x - x0, fy = y - y0;
+    int ix0 = (int)x0 % n; if (ix0 < 0) ix0 += n;
+    int iy0 = (int)y0 % n; if (iy0 < 0) iy0 += n;
+    const int ix1 = (ix0 + 1 == n) ? 0 : ix0 + 1, iy1 = (iy0 + 1 == n) ? 0 : iy0 + 1;
+    const uchar4* base = reinterpret_cast<const uchar4*>(tex) + (size_t)layer * n * n;
+    const uchar4 c00 = base[(size_t)iy0 * n + ix0], c10 = base[(size_t)iy0 * n + ix1], c01 = base[(size_t)iy1 * n + ix0], c11 = base[(size_t)iy1 * n + ix1];
+#define GM_BILERP(ch) { const float a = (float)c00.ch / 255.0f, b = (float)c10.ch / 255.0f, c = (float)c01.ch / 255.0f, d = (float)c11.ch / 255.0f; \
+                        const float r0 = a + fx * (b - a), r1 = c + fx * (d - c); out.ch = r0 + fy * (r1 - r0); }
+    GM_BILERP(x) GM_BILERP(y) GM_BILERP(z) GM_BILERP(w)
+#undef GM_BILERP
+    return out;
+}
+
 // ------------------------------------------------------------------------------------------------ block class counts
 // every thread of the block calls this once; writes blockCounts[k * nBlocks + blockIdx.x] for k = 0..3
 // (k = 3: UE4 slots whose light lies in the upper hemisphere, i.e. the entries of the shadow queue)
@@ -139,7 +167,7 @@ __global__ __launch_bounds__(kBlock) void k_logic(RenderParams p)
                 if (pix != kListEnd) prev = atomicExch(&p.listHead[pix], i);
                 p.listNext[i] = prev;
             } else {
-                // setMaterialHitProperties :79-133 (texture-free)
+                // setMaterialHitProperties :79-133
                 const uint32_t t0 = ldu(p, F_TRI_0, i), t1 = ldu(p, F_TRI_1, i), t2 = ldu(p, F_TRI_2, i), tm = ldu(p, F_TRI_MAT, i);
                 const uint32_t i0 = (uint32_t)(float)t0, i1 = (uint32_t)(float)t1, i2 = (uint32_t)(float)t2; // :82 float round trip
                 const f3 bary = ld3(p, F_BARY_X, i);
@@ -148,7 +176,29 @@ __global__ __launch_bounds__(kBlock) void k_logic(RenderParams p)
                 f3 n1 = mk3(tp[i1].normal[0], tp[i1].normal[1], tp[i1].normal[2]);
                 f3 n2 = mk3(tp[i2].normal[0], tp[i2].normal[1], tp[i2].normal[2]);
                 f3 normal = (n0 * bary.x + n1 * bary.y) + n2 * bary.z;      // :94
-                const gmupt_material m = p.scene.materials[tm < GMUPT_MAX_LIGHTS ? tm : 0u]; // :96
+                gmupt_material m = p.scene.materials[tm < GMUPT_MAX_LIGHTS ? tm : 0u]; // :96
+                if (m.textureIndices[0] >= 0 || m.textureIndices[1] >= 0 || m.textureIndices[2] >= 0) {
+                    const float tu = (tp[i0].uv[0] * bary.x + tp[i1].uv[0] * bary.y) + tp[i2].uv[0] * bary.z; // :93
+                    const float tv = (tp[i0].uv[1] * bary.x + tp[i1].uv[1] * bary.y) + tp[i2].uv[1] * bary.z;
+                    if (m.textureIndices[0] >= 0) {                        // :99-100
+                        const float4 t = sample_bilinear(p.scene, 0, tu, tv, m.textureIndices[0]);
+                        m.color[0] = t.x; m.color[1] = t.y; m.color[2] = t.z; m.color[3] = t.w;
+                    }
+                    if (m.textureIndices[1] >= 0) {                        // :102-107 metallic = .x, roughness = .y
+                        const float4 t = sample_bilinear(p.scene, 1, tu, tv, m.textureIndices[1]);
+                        m.metallic = t.x; m.roughness = t.y;
+                    }
+                    if (m.textureIndices[2] >= 0) {                        // :109-124 normal map
+                        const float4 t = sample_bilinear(p.scene, 2, tu, tv, m.textureIndices[2]);
+                        const f3 data = mk3(t.x * 2.0f - 1.0f, t.y * 2.0f - 1.0f, t.z * 2.0f - 1.0f);
+                        const f3 rayDirection = ld3(p, F_RAY_DX, i);
+                        const f3 ortNormal = dot3(normal, rayDirection) <= 0.0f ? normal : normal * -1.0f;
+                        const f3 up = dabs(ortNormal.z) < 0.999f ? mk3(0.0f, 0.0f, 1.0f) : mk3(1.0f, 0.0f, 0.0f);
+                        const f3 tangent = normalize3(cross3(up, ortNormal));
+                        const f3 bitangent = cross3(ortNormal, tangent);
+                        normal = (tangent * data.x + bitangent * data.y) + ortNormal * data.z; // :123 (not renormalised)
+                    }
+                }
                 const float rough = hmax(0.014f, m.roughness);             // :126
                 st3(p, F_MAT_R, i, mk3(m.color[0], m.color[1], m.color[2])); // :128
                 stf(p, F_MAT_METALLIC, i, m.metallic); stf(p, F_MAT_ROUGHNESS, i, rough); // :129

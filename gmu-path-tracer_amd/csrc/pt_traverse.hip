@@ -1397,7 +1397,6 @@ __global__ __launch_bounds__(kCoopBlock) void k_shadow_c(RenderParams p)
 constexpr int kDefBlock = 512;    // 8 waves share one LDS copy of the top of the tree
 constexpr int kDefStack = GMUPT_DEF_STACK;     // LDS stack entries per lane incl. the sentinel; trees deeper than kDefStack - 2 use the overflow-checked instantiation
 constexpr int kFifo = GMUPT_DEF_FIFO;          // pending leaves per lane
-constexpr int kTriBurst = 4;      // triangle tests per lane and burst
 
 template <bool OVF>
 struct DefStack {

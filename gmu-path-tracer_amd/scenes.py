@@ -37,14 +37,20 @@ DEFAULT_CAMERA = (1.0, 3.0, 8.0, 0.0, 270.0)  # Scene.cpp:59
 
 
 class _MeshBuilder:
+    """Accumulates vertices / normals / materials / triangles as a list of numpy chunks (10 M-triangle scenes stay cheap)."""
+
     def __init__(self):
         self.v, self.n, self.m, self.t = [], [], [], []
+        self.count = 0
+
+    def _add(self, verts, normals, mats, tris):
+        verts = np.asarray(verts, np.float64).reshape(-1, 3)
+        self.v.append(verts); self.n.append(np.asarray(normals, np.float64).reshape(-1, 3))
+        self.m.append(np.asarray(mats, np.uint32).reshape(-1)); self.t.append(np.asarray(tris, np.int64).reshape(-1, 3) + self.count)
+        self.count += verts.shape[0]
 
     def quad(self, p0, p1, p2, p3, normal, mat):
-        base = len(self.v)
-        for p in (p0, p1, p2, p3):
-            self.v.append(p); self.n.append(normal); self.m.append(mat)
-        self.t.append((base, base + 1, base + 2)); self.t.append((base, base + 2, base + 3))
+        self._add([p0, p1, p2, p3], [normal] * 4, [mat] * 4, [(0, 1, 2), (0, 2, 3)])
 
     def box(self, center, half, yaw_deg, mat):
         c = np.asarray(center, np.float64); h = np.asarray(half, np.float64)
@@ -59,12 +65,11 @@ class _MeshBuilder:
             self.quad(*[P(*k) for k in corners], n, mat)
 
     def mesh(self, verts, normals, tris, mat):
-        base = len(self.v)
-        self.v.extend(map(tuple, verts)); self.n.extend(map(tuple, normals)); self.m.extend([mat] * len(verts))
-        self.t.extend((int(a) + base, int(b) + base, int(c) + base) for a, b, c in tris)
+        self._add(verts, normals, np.full(len(verts), mat, np.uint32), tris)
 
     def arrays(self):
-        return (np.asarray(self.v, np.float32), np.asarray(self.n, np.float32), np.asarray(self.m, np.uint32), np.asarray(self.t, np.int32))
+        return (np.concatenate(self.v).astype(np.float32), np.concatenate(self.n).astype(np.float32),
+                np.concatenate(self.m).astype(np.uint32), np.concatenate(self.t).astype(np.int32))
 
 
 def _room(mb, lo, hi, mats, open_front=False):
@@ -196,6 +201,33 @@ def deep_chain_mesh(n=100, factor=0.6, per=2, seed=0):
             "light_count": 2, "camera": (0.0, 0.0, 0.0, 25.6, 16.7), "name": "chain%d" % n}  # at the apex, looking along the chain
 
 
+def textured_mesh(seed=5):
+    """Cornell-like room whose walls and boxes use all three texture slots (base colour, metallic/roughness, normal map) --
+    scene for the texture rows of logic.hlsl:99-124.  Planar UVs (tiling beyond [0,1] exercises WRAP), 3 layers of 16x16 texels."""
+    rng = np.random.default_rng(seed)
+    m = cornell_mesh()
+    v = m["verts"]
+    uv = np.stack([v[:, 0] * 0.37 + v[:, 1] * 0.11, v[:, 2] * 0.29 - v[:, 1] * 0.23], axis=1).astype(np.float32)
+    size, layers = 16, 3
+    yy, xx = np.mgrid[0:size, 0:size]
+    diffuse = np.zeros((layers, size, size, 4), np.uint8)
+    diffuse[0, ..., :3] = np.where(((xx // 4 + yy // 4) % 2)[..., None] == 0, (230, 230, 230), (40, 60, 200)); diffuse[0, ..., 3] = 255
+    diffuse[1] = rng.integers(30, 255, (size, size, 4)); diffuse[2, ..., 0] = 8 * xx + 60; diffuse[2, ..., 1] = 200; diffuse[2, ..., 2] = 8 * yy + 40; diffuse[2, ..., 3] = 255
+    mr = np.zeros((layers, size, size, 4), np.uint8)
+    mr[0, ..., 0] = np.where((xx % 8) < 4, 255, 0); mr[0, ..., 1] = 64 + 8 * yy       # .x metallic stripes, .y roughness ramp (quirk Q11)
+    mr[1] = rng.integers(0, 255, (size, size, 4)); mr[2, ..., 0] = 0; mr[2, ..., 1] = 230
+    nrm = np.zeros((layers, size, size, 4), np.uint8)
+    ang = rng.uniform(0, 2 * np.pi, (layers, size, size)); tilt = rng.uniform(0, 0.45, (layers, size, size))
+    nrm[..., 0] = np.clip((np.cos(ang) * tilt * 0.5 + 0.5) * 255, 0, 255); nrm[..., 1] = np.clip((np.sin(ang) * tilt * 0.5 + 0.5) * 255, 0, 255)
+    nrm[..., 2] = np.clip((np.sqrt(1 - tilt ** 2) * 0.5 + 0.5) * 255, 0, 255); nrm[..., 3] = 255
+    mats = m["materials"].copy()
+    mats[0]["textureIndices"] = (0, 0, 1)      # grey walls: checker colour, metallic stripes, bumpy
+    mats[1]["textureIndices"] = (1, -1, -1)    # red wall: colour only
+    mats[2]["textureIndices"] = (-1, 2, 2)     # green wall: rough dielectric + normal map, material colour
+    m.update({"uv": uv, "materials": mats, "tex_diffuse": diffuse, "tex_metallic_roughness": mr, "tex_normal": nrm, "name": "cornell_textured"})
+    return m
+
+
 def build_scene(mesh, sbvh_params=None):
     """BVHWrapper::buildSBVH: host SBVH build + flatten -> the buffers Renderer::draw binds (t0-t4, b1)."""
     built = capi.sbvh_build(mesh["verts"], mesh["indices"], mesh["vertex_material"], sbvh_params)
@@ -210,6 +242,8 @@ def build_scene(mesh, sbvh_params=None):
              "light_count": mesh["light_count"], "camera": mesh["camera"], "name": mesh["name"],
              "sah": built["sah"], "depth": built["depth"], "ref_triangle": built["ref_triangle"],
              "num_triangles": int(mesh["indices"].shape[0])}
+    for k in ("tex_diffuse", "tex_metallic_roughness", "tex_normal"):
+        scene[k] = mesh.get(k)
     return scene
 
 

@@ -85,7 +85,8 @@ typedef enum {
     GMUPT_BUFFER_VERTICES = 2,   /* 12 B float3;   Scene.cpp:176 mVertexBuffer (t2) */
     GMUPT_BUFFER_LIGHTS = 3,     /* 32 B x <=128;  Scene.cpp:305-329 mLightBuffer (t3); zero-padded to 128 entries */
     GMUPT_BUFFER_TRI_PROPS = 4,  /* 32 B;          Scene.cpp:177 mTriangleProperties (t4) */
-    GMUPT_BUFFER_MATERIALS = 5   /* 48 B x <=128;  Scene.cpp:194-207 mMaterialPropertyBuffer (b1) */
+    GMUPT_BUFFER_MATERIALS = 5,  /* 48 B x <=128;  Scene.cpp:194-207 mMaterialPropertyBuffer (b1) */
+    GMUPT_BUFFER_TEXTURE_ARRAY = 6 /* R8G8B8A8_UNORM Texture2DArray, square layers; created with gmupt_texture_array_create */
 } gmupt_buffer_kind;
 
 typedef struct gmupt_buffer gmupt_buffer;
@@ -95,6 +96,9 @@ int gmupt_buffer_create(gmupt_device* dev, gmupt_buffer_kind kind, const void* d
 int gmupt_buffer_update(gmupt_buffer* buf, const void* data, size_t bytes);
 void gmupt_buffer_destroy(gmupt_buffer* buf);
 size_t gmupt_buffer_size(const gmupt_buffer* buf);
+/* replaces Scene::createTextures (Source/Scene.cpp:247-303): `layers` square RGBA8 images of `size` x `size` texels, tightly packed
+ * (the caller has already resized every layer to the common size, as the reference does with avir) */
+int gmupt_texture_array_create(gmupt_device* dev, const uint8_t* rgba8, uint32_t size, uint32_t layers, gmupt_buffer** out);
 
 /* ---- renderer ---- */
 typedef struct {
@@ -117,6 +121,10 @@ void gmupt_renderer_destroy(gmupt_renderer* r);
  * The buffers must outlive the binding.  Builds the renderer's internal traversal copy of the BVH. */
 int gmupt_renderer_bind_scene(gmupt_renderer* r, const gmupt_buffer* nodes, const gmupt_buffer* triangles, const gmupt_buffer* vertices,
                               const gmupt_buffer* lights, const gmupt_buffer* tri_props, const gmupt_buffer* materials);
+/* replaces the t5..t7 / s0 slots of CSSetShaderResources + CSSetSamplers (Renderer.cpp:173-175,192): diffuse, metallicRoughness and
+ * normal Texture2DArrays, each may be NULL (an unbound slot reads zero).  Sampling is bilinear + wrap at mip 0 on UNORM8 without sRGB
+ * decode, as the reference's sampler (Scene.cpp:180-192); the filter arithmetic is stated in DESIGN.md. */
+int gmupt_renderer_bind_textures(gmupt_renderer* r, const gmupt_buffer* diffuse, const gmupt_buffer* metallic_roughness, const gmupt_buffer* normals);
 /* replaces UpdateSubresource(mCameraBuffer) (Renderer.cpp:161).  iterationCounter == 0 resets the accumulation on the next iterate. */
 int gmupt_set_camera(gmupt_renderer* r, const gmupt_camera_buffer* cam);
 /* replaces the six Dispatch(NUM_GROUPS,1,1) of Renderer::draw (Renderer.cpp:195-211): one wavefront iteration, asynchronous */

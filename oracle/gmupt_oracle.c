@@ -194,7 +194,37 @@ static void accumulate_sample(orc_renderer* r, v3 radiance, uint32_t index)
     px[3] = o_asfloat(sampleCount);
 }
 
-/* logic.hlsl:79-133 setMaterialHitProperties (texture-free: all texture indices must be -1; textures are row f3, "next") */
+/* SampleLevel(samplerState, float3(uv, layer), 0) with the reference's sampler: MIN_MAG_MIP_LINEAR, WRAP (Scene.cpp:180-192) on an
+ * R8G8B8A8_UNORM array, no sRGB decode (Scene.cpp:260).  The hardware filter is not specified bit for bit (D3D11 only asks for
+ * 8 fractional weight bits), so this build states it: texel centre convention x = u*size - 0.5, fp32 weights, lerp(a,b,t) = a + t*(b-a),
+ * horizontal pairs first, UNORM decode c / 255.  PARITY UNPINNED against the DX11 sampler. */
+static void sample_bilinear(const orc_scene* sc, int which, float u, float v, int layer, float out[4])
+{
+    out[0] = out[1] = out[2] = out[3] = 0.0f;
+    const uint8_t* tex = sc->tex[which];
+    const int n = (int)sc->texSize[which];
+    if (!tex || n <= 0 || sc->texLayers[which] == 0) return;            /* unbound SRV reads zero */
+    if (layer < 0) layer = 0;
+    if (layer >= (int)sc->texLayers[which]) layer = (int)sc->texLayers[which] - 1;
+    float x = u * (float)n - 0.5f, y = v * (float)n - 0.5f;
+    if (!(fabsf(x) < 1.0e9f)) x = 0.0f;
+    if (!(fabsf(y) < 1.0e9f)) y = 0.0f;
+    const float x0 = floorf(x), y0 = floorf(y);
+    const float fx = x - x0, fy = y - y0;
+    int ix0 = (int)x0 % n; if (ix0 < 0) ix0 += n;
+    int iy0 = (int)y0 % n; if (iy0 < 0) iy0 += n;
+    const int ix1 = (ix0 + 1 == n) ? 0 : ix0 + 1, iy1 = (iy0 + 1 == n) ? 0 : iy0 + 1;
+    const uint8_t* base = tex + (size_t)layer * n * n * 4;
+    const uint8_t* c00 = base + ((size_t)iy0 * n + ix0) * 4; const uint8_t* c10 = base + ((size_t)iy0 * n + ix1) * 4;
+    const uint8_t* c01 = base + ((size_t)iy1 * n + ix0) * 4; const uint8_t* c11 = base + ((size_t)iy1 * n + ix1) * 4;
+    for (int k = 0; k < 4; k++) {
+        const float a = (float)c00[k] / 255.0f, b = (float)c10[k] / 255.0f, c = (float)c01[k] / 255.0f, d = (float)c11[k] / 255.0f;
+        const float r0 = a + fx * (b - a), r1 = c + fx * (d - c);
+        out[k] = r0 + fy * (r1 - r0);
+    }
+}
+
+/* logic.hlsl:79-133 setMaterialHitProperties */
 static uint32_t set_material_hit_properties(orc_renderer* r, uint32_t index)
 {
     uint32_t* tri = (uint32_t*)fld(r, F_TRIANGLE, 16, index);            /* :81 */
@@ -205,10 +235,32 @@ static uint32_t set_material_hit_properties(orc_renderer* r, uint32_t index)
     v3 n0 = V(tp[i0].normal[0], tp[i0].normal[1], tp[i0].normal[2]);     /* :89-91 */
     v3 n1 = V(tp[i1].normal[0], tp[i1].normal[1], tp[i1].normal[2]);
     v3 n2 = V(tp[i2].normal[0], tp[i2].normal[1], tp[i2].normal[2]);
+    /* :93 texCoord = t0*b.x + t1*b.y + t2*b.z */
+    float tu = (tp[i0].uv[0] * bary.x + tp[i1].uv[0] * bary.y) + tp[i2].uv[0] * bary.z;
+    float tv = (tp[i0].uv[1] * bary.x + tp[i1].uv[1] * bary.y) + tp[i2].uv[1] * bary.z;
     /* :94 normal = n0*b.x + n1*b.y + n2*b.z */
     v3 normal = vadd(vadd(vscale(n0, bary.x), vscale(n1, bary.y)), vscale(n2, bary.z));
 
     orc_material m = r->scene.materials[tri[3] < ORC_MAX_LIGHTS ? tri[3] : 0]; /* :96 (cbuffer of MAX_LIGHTS entries, :8) */
+    float t[4];
+    if (m.tex[0] >= 0) {                                                 /* :99-100 diffuse: whole float4 */
+        sample_bilinear(&r->scene, 0, tu, tv, m.tex[0], t);
+        m.color[0] = t[0]; m.color[1] = t[1]; m.color[2] = t[2]; m.color[3] = t[3];
+    }
+    if (m.tex[1] >= 0) {                                                 /* :102-107 metallic = .x, roughness = .y (quirk Q11) */
+        sample_bilinear(&r->scene, 1, tu, tv, m.tex[1], t);
+        m.metallic = t[0]; m.roughness = t[1];
+    }
+    if (m.tex[2] >= 0) {                                                 /* :109-124 normal map */
+        sample_bilinear(&r->scene, 2, tu, tv, m.tex[2], t);
+        v3 data = V(t[0] * 2.0f - 1.0f, t[1] * 2.0f - 1.0f, t[2] * 2.0f - 1.0f); /* :112 */
+        v3 rayDirection = ld3(r, F_RAY_DIRECTION, index);                /* :115 */
+        v3 ortNormal = vdot(normal, rayDirection) <= 0.0f ? normal : vscale(normal, -1.0f); /* :116 */
+        v3 up = fabsf(ortNormal.z) < 0.999f ? V(0, 0, 1) : V(1, 0, 0);   /* :119 */
+        v3 tangent = vnormalize(vcross(up, ortNormal));                  /* :120 */
+        v3 bitangent = vcross(ortNormal, tangent);                       /* :121 */
+        normal = vadd(vadd(vscale(tangent, data.x), vscale(bitangent, data.y)), vscale(ortNormal, data.z)); /* :123 (not renormalised) */
+    }
     float rough = o_max(0.014f, m.roughness);                            /* :126 */
 
     st3(r, F_MAT_COLOR, index, V(m.color[0], m.color[1], m.color[2]));   /* :128 */
@@ -920,6 +972,8 @@ void orc_camera_update(orc_camera* c) /* Camera.cpp:25-88 with no mouse / keyboa
     float b = orc_msvc_rand(&c->randState) / (float)32767;
     c->cb.randomSeed[0] = a; c->cb.randomSeed[1] = b;
 }
+
+void orc_debug_sample(const orc_scene* sc, int which, float u, float v, int layer, float* out4) { sample_bilinear(sc, which, u, v, layer, out4); }
 
 /* ------------------------------------------------------------------ detmath probe */
 void orc_detmath_eval(int fn, const float* x, const float* y, float* out, uint32_t n)

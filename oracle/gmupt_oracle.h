@@ -58,6 +58,8 @@ typedef struct {
     const orc_tri_props* props;                     /* one per vertex */
     const orc_light* lights;                        /* ORC_MAX_LIGHTS entries */
     const orc_material* materials; uint32_t numMaterials;
+    /* Texture2DArray t5..t7 (diffuse, metallicRoughness, normals): RGBA8 UNORM, square layers (Scene.cpp:247-303); NULL = unbound */
+    const uint8_t* tex[3]; uint32_t texSize[3]; uint32_t texLayers[3];
 } orc_scene;
 
 typedef struct {
@@ -117,6 +119,9 @@ void orc_camera_update_resolution(orc_camera*, uint32_t width, uint32_t height);
 void orc_camera_set_pose(orc_camera*, float x, float y, float z, float pitch, float yaw);
 void orc_camera_update(orc_camera*); /* Camera::update with no input (dt irrelevant) */
 int orc_msvc_rand(uint32_t* state);
+
+/* texture filter probe */
+void orc_debug_sample(const orc_scene* sc, int which, float u, float v, int layer, float* out4);
 
 /* detmath probes for the GPU-vs-oracle bit tests */
 void orc_detmath_eval(int fn, const float* x, const float* y, float* out, uint32_t n);

