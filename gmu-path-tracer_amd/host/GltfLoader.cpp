@@ -1,0 +1,222 @@
+// Minimal glTF 2.0 reader producing what the reference gets from assimp with its post-process flags (Source/Scene.cpp:113-121):
+//   aiProcess_Triangulate (only TRIANGLES primitives are kept, like BVHWrapper.cpp:22), aiProcess_PreTransformVertices (node
+//   transforms baked into world-space vertices), aiProcess_GenSmoothNormals (only when a primitive has no normals),
+//   aiProcess_FlipUVs (v -> 1 - v), one material per primitive; material factors as read in Scene.cpp:130-146:
+//   baseColorFactor, metallicFactor, roughnessFactor, alphaMode == "BLEND" -> GLASS (Scene.cpp:138-143).
+// assimp itself is not available (headers only in the reference, binary .lib is an LFS stub), so this is a restatement of the
+// documented effect of those flags, not of assimp's code: PARITY UNPINNED.  Image decoding / texture
+// arrays are not loaded here (texture indices stay -1).
+#include "MeshData.hpp"
+#include "json_min.hpp"
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+
+namespace {
+using gmupt::Json;
+
+std::string readFile(const std::string& path, bool binary)
+{
+	std::ifstream f(path, binary ? std::ios::binary : std::ios::in);
+	if (!f.is_open()) throw std::runtime_error("Non existing scene " + path);
+	std::stringstream ss; ss << f.rdbuf();
+	return ss.str();
+}
+
+std::string decodeBase64(const std::string& in)
+{
+	std::string out; int val = 0, bits = -8;
+	for (unsigned char c : in) {
+		int d;
+		if (c >= 'A' && c <= 'Z') d = c - 'A'; else if (c >= 'a' && c <= 'z') d = c - 'a' + 26; else if (c >= '0' && c <= '9') d = c - '0' + 52;
+		else if (c == '+') d = 62; else if (c == '/') d = 63; else continue;
+		val = (val << 6) | d; bits += 6;
+		if (bits >= 0) { out.push_back(static_cast<char>((val >> bits) & 0xFF)); bits -= 8; }
+	}
+	return out;
+}
+
+struct Mat4 { double m[16]; }; // column-major like glTF
+
+Mat4 identity() { Mat4 r{}; r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0; return r; }
+Mat4 mul(const Mat4& a, const Mat4& b)
+{
+	Mat4 r{};
+	for (int c = 0; c < 4; c++) for (int rr = 0; rr < 4; rr++) { double s = 0; for (int k = 0; k < 4; k++) s += a.m[k * 4 + rr] * b.m[c * 4 + k]; r.m[c * 4 + rr] = s; }
+	return r;
+}
+Mat4 nodeMatrix(const Json& n)
+{
+	if (n.has("matrix")) { Mat4 r{}; for (int i = 0; i < 16; i++) r.m[i] = n["matrix"][i].number(); return r; }
+	double t[3] = { 0, 0, 0 }, q[4] = { 0, 0, 0, 1 }, s[3] = { 1, 1, 1 };
+	if (n.has("translation")) for (int i = 0; i < 3; i++) t[i] = n["translation"][i].number();
+	if (n.has("rotation")) for (int i = 0; i < 4; i++) q[i] = n["rotation"][i].number();
+	if (n.has("scale")) for (int i = 0; i < 3; i++) s[i] = n["scale"][i].number();
+	const double x = q[0], y = q[1], z = q[2], w = q[3];
+	Mat4 r = identity();
+	r.m[0] = (1 - 2 * (y * y + z * z)) * s[0]; r.m[1] = (2 * (x * y + z * w)) * s[0]; r.m[2] = (2 * (x * z - y * w)) * s[0];
+	r.m[4] = (2 * (x * y - z * w)) * s[1]; r.m[5] = (1 - 2 * (x * x + z * z)) * s[1]; r.m[6] = (2 * (y * z + x * w)) * s[1];
+	r.m[8] = (2 * (x * z + y * w)) * s[2]; r.m[9] = (2 * (y * z - x * w)) * s[2]; r.m[10] = (1 - 2 * (x * x + y * y)) * s[2];
+	r.m[12] = t[0]; r.m[13] = t[1]; r.m[14] = t[2];
+	return r;
+}
+
+struct Gltf
+{
+	Json doc;
+	std::vector<std::string> buffers;
+
+	// reads accessor `index` as doubles, `comps` components per element (0 = scalar indices)
+	std::vector<double> read(int index, int& count, int& comps) const
+	{
+		const Json& acc = doc["accessors"][static_cast<size_t>(index)];
+		if (acc.type != Json::Object) throw std::runtime_error("glTF: missing accessor");
+		const std::string& type = acc["type"].string();
+		comps = type == "SCALAR" ? 1 : type == "VEC2" ? 2 : type == "VEC3" ? 3 : type == "VEC4" ? 4 : 0;
+		if (!comps) throw std::runtime_error("glTF: unsupported accessor type " + type);
+		count = acc["count"].integer(0);
+		const int ctype = acc["componentType"].integer();
+		const size_t csize = (ctype == 5120 || ctype == 5121) ? 1 : (ctype == 5122 || ctype == 5123) ? 2 : 4;
+		const Json& view = doc["bufferViews"][static_cast<size_t>(acc["bufferView"].integer(0))];
+		const std::string& buf = buffers.at(static_cast<size_t>(view["buffer"].integer(0)));
+		const size_t offset = static_cast<size_t>(view["byteOffset"].number(0)) + static_cast<size_t>(acc["byteOffset"].number(0));
+		size_t stride = static_cast<size_t>(view["byteStride"].number(0));
+		if (!stride) stride = csize * static_cast<size_t>(comps);
+		if (offset + (count ? (static_cast<size_t>(count) - 1) * stride + csize * static_cast<size_t>(comps) : 0) > buf.size()) throw std::runtime_error("glTF: accessor outside its buffer");
+		std::vector<double> out(static_cast<size_t>(count) * static_cast<size_t>(comps));
+		for (int i = 0; i < count; i++)
+			for (int c = 0; c < comps; c++) {
+				const char* p = buf.data() + offset + static_cast<size_t>(i) * stride + static_cast<size_t>(c) * csize;
+				double v = 0;
+				switch (ctype) {
+				case 5120: { int8_t x; std::memcpy(&x, p, 1); v = x; } break;
+				case 5121: { uint8_t x; std::memcpy(&x, p, 1); v = x; } break;
+				case 5122: { int16_t x; std::memcpy(&x, p, 2); v = x; } break;
+				case 5123: { uint16_t x; std::memcpy(&x, p, 2); v = x; } break;
+				case 5125: { uint32_t x; std::memcpy(&x, p, 4); v = x; } break;
+				case 5126: { float x; std::memcpy(&x, p, 4); v = x; } break;
+				default: throw std::runtime_error("glTF: unsupported component type");
+				}
+				out[static_cast<size_t>(i) * static_cast<size_t>(comps) + static_cast<size_t>(c)] = v;
+			}
+		return out;
+	}
+};
+
+void addPrimitive(const Gltf& g, const Json& prim, const Mat4& world, MeshData& out)
+{
+	if (prim["mode"].integer(4) != 4) return; // only triangles are rendered (Source/BVHWrapper.cpp:21-23)
+	const Json& attrs = prim["attributes"];
+	if (!attrs.has("POSITION")) return;
+	int n = 0, comps = 0;
+	const std::vector<double> pos = g.read(attrs["POSITION"].integer(), n, comps);
+	if (comps != 3) throw std::runtime_error("glTF: POSITION must be VEC3");
+	std::vector<double> nrm, uv;
+	int nn = 0, nc = 0, un = 0, uc = 0;
+	if (attrs.has("NORMAL")) nrm = g.read(attrs["NORMAL"].integer(), nn, nc);
+	if (attrs.has("TEXCOORD_0")) uv = g.read(attrs["TEXCOORD_0"].integer(), un, uc);
+	std::vector<int32_t> idx;
+	if (prim.has("indices")) {
+		int ic = 0, icomp = 0;
+		const std::vector<double> raw = g.read(prim["indices"].integer(), ic, icomp);
+		idx.resize(raw.size());
+		for (size_t i = 0; i < raw.size(); i++) idx[i] = static_cast<int32_t>(raw[i]);
+	} else { idx.resize(static_cast<size_t>(n)); for (int i = 0; i < n; i++) idx[static_cast<size_t>(i)] = i; }
+	idx.resize(idx.size() / 3 * 3);
+	for (int32_t i : idx) if (i < 0 || i >= n) throw std::runtime_error("glTF: index outside the vertex range");
+
+	// world-space positions (aiProcess_PreTransformVertices)
+	std::vector<double> wp(static_cast<size_t>(n) * 3);
+	for (int i = 0; i < n; i++)
+		for (int r = 0; r < 3; r++)
+			wp[static_cast<size_t>(i) * 3 + static_cast<size_t>(r)] = world.m[r] * pos[static_cast<size_t>(i) * 3] + world.m[4 + r] * pos[static_cast<size_t>(i) * 3 + 1] + world.m[8 + r] * pos[static_cast<size_t>(i) * 3 + 2] + world.m[12 + r];
+	// normals: transformed by the upper 3x3 (uniform scale assumed) or generated smooth (aiProcess_GenSmoothNormals)
+	std::vector<double> wn(static_cast<size_t>(n) * 3, 0.0);
+	if (nn == n && nc == 3) {
+		for (int i = 0; i < n; i++)
+			for (int r = 0; r < 3; r++)
+				wn[static_cast<size_t>(i) * 3 + static_cast<size_t>(r)] = world.m[r] * nrm[static_cast<size_t>(i) * 3] + world.m[4 + r] * nrm[static_cast<size_t>(i) * 3 + 1] + world.m[8 + r] * nrm[static_cast<size_t>(i) * 3 + 2];
+	} else {
+		for (size_t t = 0; t + 2 < idx.size(); t += 3) {
+			const double* a = &wp[static_cast<size_t>(idx[t]) * 3]; const double* b = &wp[static_cast<size_t>(idx[t + 1]) * 3]; const double* c = &wp[static_cast<size_t>(idx[t + 2]) * 3];
+			const double e1[3] = { b[0] - a[0], b[1] - a[1], b[2] - a[2] }, e2[3] = { c[0] - a[0], c[1] - a[1], c[2] - a[2] };
+			const double fn[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
+			for (int k = 0; k < 3; k++) for (int r = 0; r < 3; r++) wn[static_cast<size_t>(idx[t + static_cast<size_t>(k)]) * 3 + static_cast<size_t>(r)] += fn[r];
+		}
+	}
+	bool isIdentity = true;
+	{ const Mat4 id = identity(); for (int k = 0; k < 16; k++) isIdentity = isIdentity && world.m[k] == id.m[k]; }
+	if (!(isIdentity && nn == n && nc == 3)) // authored normals under an identity transform are kept bit for bit
+		for (int i = 0; i < n; i++) {
+			double* v = &wn[static_cast<size_t>(i) * 3];
+			const double len = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+			if (len > 0) { v[0] /= len; v[1] /= len; v[2] /= len; }
+		}
+
+	const uint32_t material = static_cast<uint32_t>(prim["material"].integer(0) < 0 ? 0 : prim["material"].integer(0));
+	const int32_t base = static_cast<int32_t>(out.numVertices());
+	const bool hadUV = !out.texCoords.empty() || base == 0;
+	for (int i = 0; i < n; i++) {
+		for (int r = 0; r < 3; r++) { out.vertices.push_back(static_cast<float>(wp[static_cast<size_t>(i) * 3 + static_cast<size_t>(r)])); out.normals.push_back(static_cast<float>(wn[static_cast<size_t>(i) * 3 + static_cast<size_t>(r)])); }
+		out.vertexMaterial.push_back(material);
+	}
+	(void)hadUV;
+	out.texCoords.resize(out.numVertices() * 2, 0.f);
+	if (un == n && uc == 2)
+		for (int i = 0; i < n; i++) {
+			out.texCoords[(static_cast<size_t>(base) + static_cast<size_t>(i)) * 2] = static_cast<float>(uv[static_cast<size_t>(i) * 2]);
+			out.texCoords[(static_cast<size_t>(base) + static_cast<size_t>(i)) * 2 + 1] = static_cast<float>(1.0 - uv[static_cast<size_t>(i) * 2 + 1]); // aiProcess_FlipUVs
+		}
+	for (int32_t i : idx) out.indices.push_back(base + i);
+}
+
+void visitNode(const Gltf& g, int nodeIndex, const Mat4& parent, MeshData& out, int depth)
+{
+	if (depth > 64) throw std::runtime_error("glTF: node hierarchy too deep");
+	const Json& node = g.doc["nodes"][static_cast<size_t>(nodeIndex)];
+	if (node.type != Json::Object) return;
+	const Mat4 world = mul(parent, nodeMatrix(node));
+	if (node.has("mesh")) {
+		const Json& mesh = g.doc["meshes"][static_cast<size_t>(node["mesh"].integer(0))];
+		for (size_t p = 0; p < mesh["primitives"].size(); p++) addPrimitive(g, mesh["primitives"][p], world, out);
+	}
+	for (size_t c = 0; c < node["children"].size(); c++) visitNode(g, node["children"][c].integer(0), world, out, depth + 1);
+}
+}
+
+MeshData MeshData::loadGltf(const std::string& path)
+{
+	Gltf g;
+	g.doc = Json::parse(readFile(path, false));
+	const std::string dir = path.find_last_of("/\\") == std::string::npos ? std::string() : path.substr(0, path.find_last_of("/\\") + 1);
+	for (size_t i = 0; i < g.doc["buffers"].size(); i++) {
+		const std::string& uri = g.doc["buffers"][i]["uri"].string();
+		const std::string tag = "base64,";
+		if (uri.compare(0, 5, "data:") == 0 && uri.find(tag) != std::string::npos) g.buffers.push_back(decodeBase64(uri.substr(uri.find(tag) + tag.size())));
+		else g.buffers.push_back(readFile(dir + uri, true));
+	}
+	MeshData out;
+	// materials (Source/Scene.cpp:130-146)
+	for (size_t i = 0; i < g.doc["materials"].size(); i++) {
+		const Json& m = g.doc["materials"][i];
+		const Json& pbr = m["pbrMetallicRoughness"];
+		gmupt_material mp{};
+		for (int k = 0; k < 4; k++) mp.color[k] = pbr.has("baseColorFactor") ? static_cast<float>(pbr["baseColorFactor"][static_cast<size_t>(k)].number(1.0)) : 1.f;
+		mp.metallic = static_cast<float>(pbr["metallicFactor"].number(1.0));
+		mp.roughness = static_cast<float>(pbr["roughnessFactor"].number(1.0));
+		mp.refractIndex = 1.458f; mp.transmittance = 0.f;
+		mp.textureIndices[0] = mp.textureIndices[1] = mp.textureIndices[2] = -1;
+		mp.materialType = (m["alphaMode"].string() == "BLEND") ? GMUPT_MATERIAL_GLASS : GMUPT_MATERIAL_UE4; // Scene.cpp:138-143
+		out.materials.push_back(mp);
+	}
+	if (out.materials.empty()) { gmupt_material mp{}; mp.color[0] = mp.color[1] = mp.color[2] = 0.6f; mp.color[3] = 1.f; mp.metallic = 0.f; mp.roughness = 1.f; mp.textureIndices[0] = mp.textureIndices[1] = mp.textureIndices[2] = -1; out.materials.push_back(mp); }
+	const Json& scenes = g.doc["scenes"];
+	const Json& scene = scenes[static_cast<size_t>(g.doc["scene"].integer(0) < 0 ? 0 : g.doc["scene"].integer(0))];
+	if (scene.type == Json::Object) for (size_t i = 0; i < scene["nodes"].size(); i++) visitNode(g, scene["nodes"][i].integer(0), identity(), out, 0);
+	else for (size_t i = 0; i < g.doc["nodes"].size(); i++) visitNode(g, static_cast<int>(i), identity(), out, 0);
+	for (uint32_t& m : out.vertexMaterial) if (m >= out.materials.size()) m = 0;
+	if (out.numTriangles() == 0) throw std::runtime_error("glTF: no triangles in " + path);
+	return out;
+}

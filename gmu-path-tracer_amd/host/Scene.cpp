@@ -65,7 +65,8 @@ void Scene::update(float dt)
 
 void Scene::loadScene(const std::string& path)
 {
-	mScene = (path == "cornell") ? MeshData::cornell() : MeshData::load(path);
+	const bool gltf = path.size() > 5 && path.compare(path.size() - 5, 5, ".gltf") == 0;
+	mScene = (path == "cornell") ? MeshData::cornell() : gltf ? MeshData::loadGltf(path) : MeshData::load(path);
 	if (mScene.materials.size() > MAX_LIGHTS) throw std::runtime_error("More than 128 materials (logic.hlsl:8)");
 }
 

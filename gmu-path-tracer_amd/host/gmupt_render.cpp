@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <exception>
 #include <stdexcept>
 #include <string>
@@ -31,12 +32,16 @@ int main(int argc, char** argv)
 	try
 	{
 		if (buildOnly) { // host-only leg (BASELINE config 1): scene load + SBVH build + flatten, no GPU
-			const MeshData mesh = (scene == "cornell") ? MeshData::cornell() : MeshData::load(scene);
+			const bool gltf = scene.size() > 5 && scene.compare(scene.size() - 5, 5, ".gltf") == 0;
+			const MeshData mesh = (scene == "cornell") ? MeshData::cornell() : gltf ? MeshData::loadGltf(scene) : MeshData::load(scene);
 			const auto t0 = std::chrono::steady_clock::now();
 			BVHWrapper bvh(mesh);
 			const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-			std::printf("{\"triangles\": %zu, \"nodes\": %zu, \"references\": %zu, \"sah\": %.6f, \"build_s\": %.4f}\n",
-			            mesh.numTriangles(), bvh.tree().size(), bvh.indices().size(), bvh.sah(), s);
+			float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f };
+			for (size_t i = 0; i < mesh.numVertices(); i++) for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], mesh.vertices[3 * i + k]); hi[k] = std::max(hi[k], mesh.vertices[3 * i + k]); }
+			size_t glass = 0; for (const auto& m : mesh.materials) glass += m.materialType == GMUPT_MATERIAL_GLASS;
+			std::printf("{\"triangles\": %zu, \"vertices\": %zu, \"materials\": %zu, \"glass_materials\": %zu, \"nodes\": %zu, \"references\": %zu, \"sah\": %.6f, \"build_s\": %.4f, \"bbox\": [%.6f, %.6f, %.6f, %.6f, %.6f, %.6f]}\n",
+			            mesh.numTriangles(), mesh.numVertices(), mesh.materials.size(), glass, bvh.tree().size(), bvh.indices().size(), bvh.sah(), s, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]);
 			return 0;
 		}
 		Renderer renderer(nullptr, { w, h }, scene, 0, pool, live);

@@ -268,3 +268,68 @@ def save_gmesh(mesh, path, params_path=None):
                 L = mesh["lights"][i]
                 row = list(L["position"]) + [L["falloff"]] + list(L["emission"]) + [L["radius"]]
                 f.write(", ".join(repr(float(v)) for v in row) + "\n")
+
+
+def save_gltf(mesh, path, node_transform=None, with_normals=True):
+    """Writes `mesh` as glTF 2.0 (.gltf + .bin next to it), one TRIANGLES primitive per material, and returns the mesh in the vertex
+    order it was written (what a loader reproduces).  UVs are stored un-flipped (v -> 1 - v), as glTF files are before the reference's
+    aiProcess_FlipUVs.  Optionally writes a sibling .params file (camera + lights) like save_gmesh."""
+    import json as _json
+    tri_mat = mesh["vertex_material"][mesh["indices"][:, 0]]
+    verts, normals, uvs, vmat, tris = [], [], [], [], []
+    prims, accessors, views, blob = [], [], [], bytearray()
+
+    def add_view(data, target=None):
+        while len(blob) % 4:
+            blob.append(0)
+        views.append({"buffer": 0, "byteOffset": len(blob), "byteLength": len(data)})
+        if target:
+            views[-1]["target"] = target
+        blob.extend(data)
+        return len(views) - 1
+
+    base = 0
+    for m in range(mesh["materials"].shape[0]):
+        sel = np.where(tri_mat == m)[0]
+        if sel.size == 0:
+            continue
+        used, inv = np.unique(mesh["indices"][sel].reshape(-1), return_inverse=True)
+        p = mesh["verts"][used].astype(np.float32); n = mesh["normals"][used].astype(np.float32)
+        uv = (mesh["uv"][used] if "uv" in mesh else np.zeros((used.size, 2))).astype(np.float32)
+        idx = inv.reshape(-1, 3).astype(np.uint32)
+        attrs = {}
+        accessors.append({"bufferView": add_view(p.tobytes(), 34962), "componentType": 5126, "count": int(used.size), "type": "VEC3",
+                          "min": p.min(0).tolist(), "max": p.max(0).tolist()}); attrs["POSITION"] = len(accessors) - 1
+        if with_normals:
+            accessors.append({"bufferView": add_view(n.tobytes(), 34962), "componentType": 5126, "count": int(used.size), "type": "VEC3"}); attrs["NORMAL"] = len(accessors) - 1
+        uv_file = uv.copy(); uv_file[:, 1] = 1.0 - uv_file[:, 1]
+        accessors.append({"bufferView": add_view(uv_file.astype(np.float32).tobytes(), 34962), "componentType": 5126, "count": int(used.size), "type": "VEC2"}); attrs["TEXCOORD_0"] = len(accessors) - 1
+        accessors.append({"bufferView": add_view(idx.tobytes(), 34963), "componentType": 5125, "count": int(idx.size), "type": "SCALAR"})
+        prims.append({"attributes": attrs, "indices": len(accessors) - 1, "material": m, "mode": 4})
+        verts.append(p); normals.append(n); uvs.append((1.0 - uv_file[:, 1:2]) * 1.0); vmat.append(np.full(used.size, m, np.uint32)); tris.append(idx.astype(np.int32) + base)
+        uvs[-1] = np.concatenate([uv_file[:, 0:1], 1.0 - uv_file[:, 1:2]], axis=1).astype(np.float32)
+        base += used.size
+    mats = []
+    for mm in mesh["materials"]:
+        d = {"pbrMetallicRoughness": {"baseColorFactor": [float(v) for v in mm["color"]], "metallicFactor": float(mm["metallic"]), "roughnessFactor": float(mm["roughness"])}}
+        if int(mm["materialType"]) == capi.MATERIAL_GLASS:
+            d["alphaMode"] = "BLEND"
+        mats.append(d)
+    node = {"mesh": 0}
+    if node_transform:
+        node.update(node_transform)
+    doc = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}], "nodes": [node], "meshes": [{"primitives": prims}], "materials": mats,
+           "accessors": accessors, "bufferViews": views, "buffers": [{"uri": path.rsplit("/", 1)[-1].rsplit(".", 1)[0] + ".bin", "byteLength": len(blob)}]}
+    with open(path, "w") as f:
+        _json.dump(doc, f)
+    with open(path.rsplit(".", 1)[0] + ".bin", "wb") as f:
+        f.write(bytes(blob))
+    with open(path.rsplit(".", 1)[0] + ".params", "w") as f:
+        f.write(", ".join(repr(float(v)) for v in mesh["camera"]) + "\n")
+        for i in range(mesh["light_count"]):
+            L = mesh["lights"][i]
+            f.write(", ".join(repr(float(v)) for v in list(L["position"]) + [L["falloff"]] + list(L["emission"]) + [L["radius"]]) + "\n")
+    out = dict(mesh)
+    out.update({"verts": np.concatenate(verts), "normals": np.concatenate(normals), "uv": np.concatenate(uvs), "vertex_material": np.concatenate(vmat),
+                "indices": np.concatenate(tris)})
+    return out

@@ -92,7 +92,8 @@ typedef enum {
 typedef struct gmupt_buffer gmupt_buffer;
 /* replaces createBuffer<T> (Include/Util.hpp:17-43) + ID3D11Device::CreateBuffer with initial data */
 int gmupt_buffer_create(gmupt_device* dev, gmupt_buffer_kind kind, const void* data, size_t bytes, gmupt_buffer** out);
-/* replaces the light-buffer re-upload of the GUI (Source/GUI.cpp:125-130): UpdateSubresource on an existing buffer */
+/* replaces the light-buffer re-upload of the GUI (Source/GUI.cpp:125-130): UpdateSubresource on an existing buffer.
+ * After updating node / triangle / vertex buffers call gmupt_renderer_bind_scene again (it rebuilds the traversal copy). */
 int gmupt_buffer_update(gmupt_buffer* buf, const void* data, size_t bytes);
 void gmupt_buffer_destroy(gmupt_buffer* buf);
 size_t gmupt_buffer_size(const gmupt_buffer* buf);

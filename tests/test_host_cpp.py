@@ -31,6 +31,28 @@ def test_build_only_matches_python_builder(exe, pkg, cornell_scene, tmp_path):
     assert out["nodes"] == ref["nodes"].shape[0] and out["references"] == ref["tris"].shape[0] and abs(out["sah"] - ref["sah"]) < 1e-3
 
 
+def test_gltf_loader_matches_written_mesh(exe, pkg, tmp_path):
+    # f1: Scene(device, "x.gltf") path -- geometry, material factors, BLEND -> glass, flipped UVs, .params sibling
+    mesh = pkg.scenes.random_triangles_mesh(1500, seed=4)      # three materials, one of them glass
+    path = str(tmp_path / "scene.gltf")
+    written = pkg.scenes.save_gltf(mesh, path)
+    out = json.loads(subprocess.run([exe, "--build-only", "--scene", path], check=True, capture_output=True, text=True).stdout)
+    ref = pkg.scenes.build_scene(written)
+    assert out["triangles"] == written["indices"].shape[0] and out["vertices"] == written["verts"].shape[0]
+    assert out["materials"] == mesh["materials"].shape[0] and out["glass_materials"] == int((mesh["materials"]["materialType"] == 1).sum()) > 0
+    assert out["nodes"] == ref["nodes"].shape[0] and out["references"] == ref["tris"].shape[0] and abs(out["sah"] - ref["sah"]) < 1e-3
+    # node transform (translation, rotation about y, uniform scale) is baked into the vertices: aiProcess_PreTransformVertices
+    ang = np.deg2rad(30.0)
+    tr = {"translation": [1.0, 2.0, -3.0], "rotation": [0.0, float(np.sin(ang / 2)), 0.0, float(np.cos(ang / 2))], "scale": [2.0, 2.0, 2.0]}
+    path2 = str(tmp_path / "moved.gltf")
+    w2 = pkg.scenes.save_gltf(pkg.scenes.cornell_mesh(), path2, node_transform=tr, with_normals=False)
+    out2 = json.loads(subprocess.run([exe, "--build-only", "--scene", path2], check=True, capture_output=True, text=True).stdout)
+    Rm = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    moved = (w2["verts"].astype(np.float64) * 2.0) @ Rm.T + np.array([1.0, 2.0, -3.0])
+    assert np.allclose(out2["bbox"], np.concatenate([moved.min(0), moved.max(0)]), atol=1e-4)
+    assert out2["triangles"] == 34
+
+
 def test_missing_scene_is_a_runtime_error(exe):
     r = subprocess.run([exe, "--build-only", "--scene", "/nonexistent/x.gmesh"], capture_output=True, text=True)
     assert r.returncode != 0 and "Non existing scene" in r.stderr            # wording of Source/Scene.cpp:79, exit path of main.cpp:19-23
@@ -38,10 +60,10 @@ def test_missing_scene_is_a_runtime_error(exe):
 
 @pytest.mark.gpu
 def test_cpp_renderer_equals_capi_render(exe, pkg, device, tmp_path):
-    # Renderer::update()/draw() frames through the C++ classes == the same frames driven through the C-ABI from Python
-    mesh = pkg.scenes.spheres_mesh(n_spheres=12, subdiv=2, seed=7, floor_quads=4)
-    path = str(tmp_path / "s12.gmesh")
-    pkg.scenes.save_gmesh(mesh, path, str(tmp_path / "s12.params"))
+    # Renderer::update()/draw() frames through the C++ classes (scene loaded from glTF + .params) == the same frames driven
+    # through the C-ABI from Python
+    mesh = pkg.scenes.save_gltf(pkg.scenes.random_triangles_mesh(1500, seed=4), str(tmp_path / "s12.gltf"))
+    path = str(tmp_path / "s12.gltf")
     W, H, P, frames = 48, 27, 4096, 20
     dump = str(tmp_path / "fb.f32")
     subprocess.run([exe, "--scene", path, "--size", "%dx%d" % (W, H), "--frames", str(frames), "--pool", str(P), "--live", str(P),
