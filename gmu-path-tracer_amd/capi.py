@@ -129,8 +129,8 @@ def lib():
     """Loads libgmupt.so (building it first if the sources are newer).  Fails loudly when it cannot."""
     global _lib
     if _lib is None:
-        path = _build.LIB
-        if not os.path.exists(path) or (os.path.exists("/opt/rocm/bin/hipcc") and _build.needs_build()):
+        path = os.environ.get("GMUPT_LIB") or _build.LIB   # GMUPT_LIB: A/B timing of differently configured builds
+        if not os.environ.get("GMUPT_LIB") and (not os.path.exists(path) or (os.path.exists("/opt/rocm/bin/hipcc") and _build.needs_build())):
             path = _build.build()
         handle = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():

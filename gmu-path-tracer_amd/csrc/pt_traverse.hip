@@ -269,6 +269,17 @@ __device__ __forceinline__ float ray_box(float mnx, float mny, float mnz, float 
     return (t1 >= t0) ? (t0 > 0.0f ? t0 : t1) : -1.0f;
 }
 
+// as ray_box, but also returns the entry distance max(t0, 0) (0 when the origin is inside the box)
+__device__ __forceinline__ float ray_box_entry(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, f3 o, f3 invdir, float& entry)
+{
+    const float fx = (mxx - o.x) * invdir.x, fy = (mxy - o.y) * invdir.y, fz = (mxz - o.z) * invdir.z;
+    const float nx = (mnx - o.x) * invdir.x, ny = (mny - o.y) * invdir.y, nz = (mnz - o.z) * invdir.z;
+    const float t1 = __builtin_fminf(__builtin_fmaxf(fx, nx), __builtin_fminf(__builtin_fmaxf(fy, ny), __builtin_fmaxf(fz, nz)));
+    const float t0 = __builtin_fmaxf(__builtin_fminf(fx, nx), __builtin_fmaxf(__builtin_fminf(fy, ny), __builtin_fminf(fz, nz)));
+    entry = __builtin_fmaxf(t0, 0.0f);
+    return (t1 >= t0) ? (t0 > 0.0f ? t0 : t1) : -1.0f;
+}
+
 struct PackedStack {
     int* lds; int* ovf; uint32_t ovfStride; uint32_t ptr;
     __device__ __forceinline__ void push(int v, DevStats* st)
@@ -1394,7 +1405,10 @@ __global__ __launch_bounds__(kCoopBlock) void k_shadow_c(RenderParams p)
 // runs its triangle tests in bursts when most lanes have leaves pending.  Each ray's leaves are still tested in visit order
 // (FIFO) with the strict `t < distance` rule, so ties resolve exactly as in the reference; the shadow ray (any hit) may
 // walk a little further than needed before its occluder is found, which cannot change its boolean result.
-constexpr int kDefBlock = 512;    // 8 waves share one LDS copy of the top of the tree
+#ifndef GMUPT_DEF_BLOCK
+#define GMUPT_DEF_BLOCK 512
+#endif
+constexpr int kDefBlock = GMUPT_DEF_BLOCK;    // the waves of a workgroup share one LDS copy of the top of the tree
 constexpr int kDefStack = GMUPT_DEF_STACK;     // LDS stack entries per lane incl. the sentinel; trees deeper than kDefStack - 2 use the overflow-checked instantiation
 constexpr int kFifo = GMUPT_DEF_FIFO;          // pending leaves per lane
 
@@ -1433,6 +1447,31 @@ __device__ __forceinline__ int inner_step_d(const TravScene& ts, const float4* s
     const float rightHit = ray_box(b.z, b.w, c.x, c.y, c.z, c.w, o, invdir);
     const bool l = leftHit > 0.0f, r = rightHit > 0.0f;
     const bool swap = leftHit > rightHit;            // extensionRayCast.hlsl:136: nearer child first, the other one deferred
+    if (l && r) { stk.push(swap ? d.x : d.y, dst); return swap ? d.y : d.x; }
+    if (l | r) return l ? d.x : d.y;
+    return stk.pop();
+}
+
+// Shadow (any-hit) inner step.  The result of a shadow ray is an OR over triangle tests, accepted only when |d t| < lightDistance
+// (shadowRayCast.hlsl:41-45,89).  A child box the ray ENTERS beyond the light cannot hold such a hit (a hit point lies in some
+// leaf box of its triangle, clipped boxes of spatial splits included), so it is skipped; `limitT` carries a relative margin far
+// above fp32 rounding of the slab test.  The visit order stays near-first.  The closest-hit kernel must not do this (quirk Q14).
+template <bool OVF, bool TOP>
+__device__ __forceinline__ int inner_step_shadow(const TravScene& ts, const float4* s_top, int cur, f3 o, f3 invdir, float limitT, DefStack<OVF>& stk, DevStats* dst)
+{
+    float4 a, b, c; int4 d;
+    if (TOP && (uint32_t)cur < ts.topCount) {
+        const float4* n = s_top + cur * 4;
+        a = n[0]; b = n[1]; c = n[2]; d = *reinterpret_cast<const int4*>(n + 3);
+    } else {
+        const float4* n = reinterpret_cast<const float4*>(ts.nodes + cur);
+        a = n[0]; b = n[1]; c = n[2]; d = *reinterpret_cast<const int4*>(n + 3);
+    }
+    float le, re;
+    const float leftHit = ray_box_entry(a.x, a.y, a.z, a.w, b.x, b.y, o, invdir, le);
+    const float rightHit = ray_box_entry(b.z, b.w, c.x, c.y, c.z, c.w, o, invdir, re);
+    const bool l = leftHit > 0.0f && le <= limitT, r = rightHit > 0.0f && re <= limitT;
+    const bool swap = leftHit > rightHit;
     if (l && r) { stk.push(swap ? d.x : d.y, dst); return swap ? d.y : d.x; }
     if (l | r) return l ? d.x : d.y;
     return stk.pop();
@@ -1591,6 +1630,7 @@ __global__ __launch_bounds__(kDefBlock) void k_shadow_d(RenderParams p)
     DefStack<OVF> stk; stk.lds = s_stack + threadIdx.x; stk.ovf = p.ovfStack + gtid; stk.ovfStride = p.ovfStride; stk.ptr = 1;
     s_stack[threadIdx.x] = kDone;
     int* fifo = s_fifo + threadIdx.x;
+    const float sceneEps = 1.0e-4f * (dabs(p.trav.rootMax[0] - p.trav.rootMin[0]) + dabs(p.trav.rootMax[1] - p.trav.rootMin[1]) + dabs(p.trav.rootMax[2] - p.trav.rootMin[2]));
     TravCount tc = { 0, 0, 0 }; uint32_t rays = 0, wIn = 0, wTr = 0;
     const TravScene& ts = p.trav;
     const uint32_t* qSh = p.queues + (size_t)Q_SHADOW_RAY * p.P;
@@ -1600,7 +1640,7 @@ __global__ __launch_bounds__(kDefBlock) void k_shadow_d(RenderParams p)
     bool haveRay = false, occluded = false;
     uint32_t index = 0;
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), invdir = mk3(0, 0, 0);
-    float lightDistance = 0.0f;
+    float lightDistance = 0.0f, limitT = 0.0f;
     int cur = kDone;
     uint32_t qHead = 0, qCount = 0;
     int ti = -1;
@@ -1627,6 +1667,7 @@ __global__ __launch_bounds__(kDefBlock) void k_shadow_d(RenderParams p)
                     o = ld3(p, F_SH_OX, index); d = ld3(p, F_SH_DX, index);  // :162-163
                     lightDistance = ldf(p, F_LIGHT_DIST, index);             // :164
                     invdir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    limitT = (lightDistance / length3(d)) * 1.0001f + sceneEps; // parametric distance of the light, with margin
                     stk.reset(); qHead = 0; qCount = 0; ti = -1;
                     cur = (ray_box(ts.rootMin[0], ts.rootMin[1], ts.rootMin[2], ts.rootMax[0], ts.rootMax[1], ts.rootMax[2], o, invdir) > 0.0f) ? ts.rootDesc : kDone;
                 }
@@ -1638,7 +1679,7 @@ __global__ __launch_bounds__(kDefBlock) void k_shadow_d(RenderParams p)
         for (int rep = 0; rep < REPS; rep++) {
             if (cur >= 0) {
                 if (STATS) { tc.inner++; if (prefix_rank(__ballot(1)) == 0) wIn++; }
-                cur = inner_step_d<OVF, TOP>(ts, s_top, cur, o, invdir, stk, p.stats);
+                cur = p.shadowPrune ? inner_step_shadow<OVF, TOP>(ts, s_top, cur, o, invdir, limitT, stk, p.stats) : inner_step_d<OVF, TOP>(ts, s_top, cur, o, invdir, stk, p.stats);
             }
             if (cur < 0 && cur != kDone && qCount < (uint32_t)kFifo) {
                 if (STATS) tc.leaves++;
