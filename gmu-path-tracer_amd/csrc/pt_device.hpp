@@ -119,6 +119,7 @@ struct RenderParams {
     uint32_t raysPerWave;  // queue entries owned by one wave of the persistent ray-cast kernels
     uint32_t* travCounters; // [0] extension, [1] shadow: next unassigned queue entry (zeroed by k_scan every iteration)
     uint32_t travGridBlocks; // persistent ray-cast grid
+    uint32_t extendPrune;  // 1: the extension ray skips boxes it enters beyond its current closest hit (see pt_traverse.hip)
     uint32_t shadowPrune;  // 1: the shadow ray skips boxes it enters beyond the light (cannot change its boolean result)
     uint32_t tuneRefill, tuneTriThresh; // lane-refill / triangle-burst thresholds of the deferred-leaf kernels
     gmupt_camera_buffer cam;

@@ -1452,12 +1452,18 @@ __device__ __forceinline__ int inner_step_d(const TravScene& ts, const float4* s
     return stk.pop();
 }
 
-// Shadow (any-hit) inner step.  The result of a shadow ray is an OR over triangle tests, accepted only when |d t| < lightDistance
-// (shadowRayCast.hlsl:41-45,89).  A child box the ray ENTERS beyond the light cannot hold such a hit (a hit point lies in some
-// leaf box of its triangle, clipped boxes of spatial splits included), so it is skipped; `limitT` carries a relative margin far
-// above fp32 rounding of the slab test.  The visit order stays near-first.  The closest-hit kernel must not do this (quirk Q14).
+// OPT-IN inner step with distance pruning (GMUPT_EXTEND_PRUNE=1 / GMUPT_SHADOW_PRUNE=1; both default to 0).
+// In exact arithmetic a child box that the ray ENTERS beyond `limitT` (the current closest hit, or the light for a shadow ray; both
+// with a relative margin) cannot hold a triangle test that changes the result: every accepted hit point lies inside some leaf box of
+// its triangle (clipped boxes of spatial splits included), the visit order of the remaining nodes is unchanged, and the strict
+// `t < distance` rule makes ties irrelevant.  In binary32 the reference's own Moeller-Trumbore test is noisy for rays within ~1e-7
+// rad of a large triangle's plane (|det| just above the 1e-8 cut-off is rounding noise), and such a test can return a `t` far from
+// the geometry -- the un-pruned reference then "finds" a hit that a pruned walk never tests.  Measured on the bench scene: bit-
+// identical path state and framebuffer over 3000 full-size iterations (6.3 G rays, tools/prune_check.py) with both prunings on,
+// k_extend 0.93 -> 0.78 ms and k_shadow 0.60 -> 0.49 ms; but it is not provable, so the default keeps the reference's
+// no-pruning rule (quirk Q14) and parity claims are made for the default only.
 template <bool OVF, bool TOP>
-__device__ __forceinline__ int inner_step_shadow(const TravScene& ts, const float4* s_top, int cur, f3 o, f3 invdir, float limitT, DefStack<OVF>& stk, DevStats* dst)
+__device__ __forceinline__ int inner_step_pruned(const TravScene& ts, const float4* s_top, int cur, f3 o, f3 invdir, float limitT, DefStack<OVF>& stk, DevStats* dst)
 {
     float4 a, b, c; int4 d;
     if (TOP && (uint32_t)cur < ts.topCount) {
@@ -1493,6 +1499,7 @@ __global__ __launch_bounds__(kDefBlock) void k_extend_d(RenderParams p)
     DefStack<OVF> stk; stk.lds = s_stack + threadIdx.x; stk.ovf = p.ovfStack + gtid; stk.ovfStride = p.ovfStride; stk.ptr = 1;
     s_stack[threadIdx.x] = kDone;
     int* fifo = s_fifo + threadIdx.x;
+    const float sceneEps = 1.0e-4f * (dabs(p.trav.rootMax[0] - p.trav.rootMin[0]) + dabs(p.trav.rootMax[1] - p.trav.rootMin[1]) + dabs(p.trav.rootMax[2] - p.trav.rootMin[2]));
     TravCount tc = { 0, 0, 0 }; uint32_t rays = 0, wIn = 0, wTr = 0;
     const TravScene& ts = p.trav;
     const uint32_t count = p.qc[QC_EXT_COUNT];
@@ -1575,7 +1582,8 @@ __global__ __launch_bounds__(kDefBlock) void k_extend_d(RenderParams p)
         for (int rep = 0; rep < REPS; rep++) {
             if (cur >= 0) {
                 if (STATS) { tc.inner++; if (prefix_rank(__ballot(1)) == 0) wIn++; }
-                cur = inner_step_d<OVF, TOP>(ts, s_top, cur, o, invdir, stk, p.stats);
+                cur = p.extendPrune ? inner_step_pruned<OVF, TOP>(ts, s_top, cur, o, invdir, distance * 1.0001f + sceneEps, stk, p.stats)
+                                    : inner_step_d<OVF, TOP>(ts, s_top, cur, o, invdir, stk, p.stats);
             }
             if (cur < 0 && cur != kDone && qCount < (uint32_t)kFifo) {
                 if (STATS) tc.leaves++;
@@ -1679,7 +1687,7 @@ __global__ __launch_bounds__(kDefBlock) void k_shadow_d(RenderParams p)
         for (int rep = 0; rep < REPS; rep++) {
             if (cur >= 0) {
                 if (STATS) { tc.inner++; if (prefix_rank(__ballot(1)) == 0) wIn++; }
-                cur = p.shadowPrune ? inner_step_shadow<OVF, TOP>(ts, s_top, cur, o, invdir, limitT, stk, p.stats) : inner_step_d<OVF, TOP>(ts, s_top, cur, o, invdir, stk, p.stats);
+                cur = p.shadowPrune ? inner_step_pruned<OVF, TOP>(ts, s_top, cur, o, invdir, limitT, stk, p.stats) : inner_step_d<OVF, TOP>(ts, s_top, cur, o, invdir, stk, p.stats);
             }
             if (cur < 0 && cur != kDone && qCount < (uint32_t)kFifo) {
                 if (STATS) tc.leaves++;

@@ -103,12 +103,13 @@ def test_traversal_statistics_match(pkg, device, soup_scene):
     hip.close(); sb.close(); orc.close()
 
 
-def test_shadow_pruning_does_not_change_results(pkg, device, soup_scene, monkeypatch):
-    # skipping boxes that a shadow ray enters beyond its light must leave every pixel bit-identical
+@pytest.mark.parametrize("var", ["GMUPT_SHADOW_PRUNE", "GMUPT_EXTEND_PRUNE"])
+def test_optin_pruning_is_neutral_here(pkg, device, soup_scene, monkeypatch, var):
+    # the opt-in distance prunings (off by default, see pt_traverse.hip) leave every bit unchanged on this scene
     W, H, P = 48, 27, 4096
     fbs = []
     for prune in ("0", "1"):
-        monkeypatch.setenv("GMUPT_SHADOW_PRUNE", prune)
+        monkeypatch.setenv(var, prune)
         sb = pkg.capi.SceneBuffers(device, soup_scene)
         r = pkg.capi.Renderer(device, W, H, pool_paths=P); r.bind_scene(sb)
         cam = pkg.capi.Camera(W, H); cam.set_pose(*soup_scene["camera"])
