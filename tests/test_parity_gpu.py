@@ -87,6 +87,31 @@ def test_deep_tree_uses_stack_overflow_path(pkg, device):
     hip.close(); sb.close(); orc.close()
 
 
+def test_edge_cases_odd_pool_single_triangle_and_no_geometry_hit(pkg, device):
+    # pool / live counts that are not multiples of the workgroup size, a BVH whose root is a leaf, rays that miss everything (envColor path)
+    capi = pkg.capi
+    mesh = pkg.scenes.cornell_mesh()
+    one = {**mesh, "verts": np.array([[-3, 0, -2], [3, 0, -2], [0, 5, -2]], np.float32), "normals": np.array([[0, 0, 1]] * 3, np.float32),
+           "vertex_material": np.zeros(3, np.uint32), "indices": np.array([[0, 1, 2]], np.int32), "name": "one_triangle"}
+    scene = pkg.scenes.build_scene(one)
+    assert scene["nodes"].shape[0] == 1 and scene["nodes"]["isLeaf"][0] == 1
+    W, H, P, L = 40, 24, 1000, 900
+    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, scene, W, H, P, live=L)
+    for it in range(14):
+        PU.step_both(orc, hip, ocam, hcam)
+        _assert_same(orc, hip, P, L, it)
+    fb = hip.framebuffer()
+    assert int(fb[..., 3].view(np.uint32).sum()) == hip.stats().paths_completed > 0
+    hip.close(); sb.close(); orc.close()
+    # zero lights sampled (lightCount = 0): light 0 of the zero-padded table is picked, nothing crashes, still bit-identical
+    scene2 = pkg.scenes.build_scene(mesh); scene2["light_count"] = 0
+    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, scene2, 32, 18, 777)
+    for it in range(8):
+        PU.step_both(orc, hip, ocam, hcam)
+    _assert_same(orc, hip, 777, 777, 7)
+    hip.close(); sb.close(); orc.close()
+
+
 def test_traversal_statistics_match(pkg, device, soup_scene):
     # the counting variant of the ray-cast kernels reports the same inner-node / triangle-test totals as the oracle for the
     # extension stage (the visited set does not depend on the traversal order)
