@@ -117,7 +117,7 @@ def main():
     step(r, cam, args.prewarm + args.warmup)
     r.synchronize()
     r.reset_stats()
-    r.enable_timing(not args.no_stage_timing)
+    r.enable_timing(0 if args.no_stage_timing else 2)   # two HIP events per step, around the extension ray cast only
     tile_t = torch.empty((rows, W, 4), dtype=torch.float32, device="cuda")
 
     barrier()
@@ -129,7 +129,10 @@ def main():
     elapsed = time.perf_counter() - t_start
 
     st = r.stats()
-    r.enable_timing(False)
+    r.enable_timing(0)
+    ext_ms = st.ms_extend / max(st.timed_iterations, 1)
+    # per-stage breakdown: a short untimed continuation with events around every stage group
+    r.reset_stats(); r.enable_timing(1); step(r, cam, 50); stb = r.stats(); r.enable_timing(0)
     completed = torch.tensor([float(st.paths_completed), float(st.segments)], dtype=torch.float64, device=coll_dev)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
     if world > 1:
@@ -137,7 +140,6 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     total_paths, total_segments = completed.tolist()
     elapsed = float(tmax.item())
-    ext_ms = st.ms_extend / max(st.timed_iterations, 1)
 
     roofline = None
     if rank == 0 and not args.no_roofline:
@@ -182,9 +184,9 @@ def main():
                        "pool_paths_per_gpu": args.pool, "prewarm_steps": args.prewarm, "tiling": "row bands x%d" % world,
                        "parallelism": "tile%d" % world},
             "msegments_per_s": round(total_segments / elapsed / 1e6, 1),
-            "stage_ms": {"logic": round(st.ms_logic / max(st.timed_iterations, 1), 4), "scan": round(st.ms_scan / max(st.timed_iterations, 1), 4),
-                         "material": round(st.ms_material / max(st.timed_iterations, 1), 4), "extend": round(ext_ms, 4),
-                         "shadow": round(st.ms_shadow / max(st.timed_iterations, 1), 4)},
+            "stage_ms": {"logic": round(stb.ms_logic / max(stb.timed_iterations, 1), 4), "scan": round(stb.ms_scan / max(stb.timed_iterations, 1), 4),
+                         "material": round(stb.ms_material / max(stb.timed_iterations, 1), 4), "extend": round(ext_ms, 4),
+                         "shadow": round(stb.ms_shadow / max(stb.timed_iterations, 1), 4)},
             "scene_build_s": round(build_s, 2),
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

@@ -310,8 +310,8 @@ class Renderer:
     def reset_stats(self):
         _check(lib().gmupt_reset_stats(self.h))
 
-    def enable_timing(self, on=True):
-        _check(lib().gmupt_enable_timing(self.h, 1 if on else 0))
+    def enable_timing(self, mode=1):
+        _check(lib().gmupt_enable_timing(self.h, int(mode)))
 
     def render_budget(self, camera, max_iterations=1 << 20):
         it = C.c_uint32(0)

@@ -156,7 +156,7 @@ extern "C" void gmupt_buffer_destroy(gmupt_buffer* buf)
 extern "C" size_t gmupt_buffer_size(const gmupt_buffer* buf) { return buf ? buf->bytes : 0; }
 
 // ------------------------------------------------------------------------------------------------ renderer
-struct StageEvents { hipEvent_t e[6]; };
+struct StageEvents { hipEvent_t e[6]; bool extOnly = false; };
 
 struct gmupt_renderer {
     gmupt_device* dev = nullptr;
@@ -167,7 +167,7 @@ struct gmupt_renderer {
     uint64_t iterations = 0;
     uint32_t travBlocks = 0;
     // timing
-    bool timing = false;
+    int timing = 0; // 0 off, 1 all stages, 2 only the extension ray cast (two events per iteration)
     std::vector<StageEvents> evPool; size_t evUsed = 0;
     double msStage[5] = { 0, 0, 0, 0, 0 }; uint64_t timedIters = 0;
     std::vector<void*> allocs;
@@ -421,6 +421,7 @@ static int resolve_timing(gmupt_renderer* r)
     HIP_TRY(hipStreamSynchronize(r->stream));
     for (size_t k = 0; k < r->evUsed; k++) {
         for (int sidx = 0; sidx < 5; sidx++) {
+            if (r->evPool[k].extOnly && sidx != 3) continue;
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, r->evPool[k].e[sidx], r->evPool[k].e[sidx + 1]));
             r->msStage[sidx] += ms;
@@ -440,25 +441,27 @@ static int run_iteration(gmupt_renderer* r, bool doShade, bool doExtend, bool do
     const int clearFrame = (p.cam.iterationCounter == 0) ? 1 : 0; // logic.hlsl:206
     const bool stats = r->desc.collect_stats != 0;
     StageEvents* ev = nullptr;
+    const bool extOnly = r->timing == 2;
     if (r->timing && doShade && doExtend && doShadow) {
         if (r->evUsed == r->evPool.size()) {
             if (r->evPool.size() >= 4096) { int rc = resolve_timing(r); if (rc != GMUPT_OK) return rc; }
             else { StageEvents se; for (auto& e : se.e) HIP_TRY(hipEventCreate(&e)); r->evPool.push_back(se); }
         }
         ev = &r->evPool[r->evUsed++];
-        HIP_TRY(hipEventRecord(ev->e[0], r->stream));
+        ev->extOnly = extOnly;
+        if (!extOnly) HIP_TRY(hipEventRecord(ev->e[0], r->stream));
     }
     if (doShade) {
         if (clearFrame) launch_clear(p, r->stream); else launch_logic(p, r->stream);
-        if (ev) HIP_TRY(hipEventRecord(ev->e[1], r->stream));
+        if (ev && !extOnly) HIP_TRY(hipEventRecord(ev->e[1], r->stream));
         launch_scan(p, clearFrame, r->stream);
-        if (ev) HIP_TRY(hipEventRecord(ev->e[2], r->stream));
+        if (ev && !extOnly) HIP_TRY(hipEventRecord(ev->e[2], r->stream));
         launch_material(p, clearFrame, r->stream);
         if (ev) HIP_TRY(hipEventRecord(ev->e[3], r->stream));
     }
     if (!doShade) HIP_TRY(hipMemsetAsync(p.travCounters, 0, 16, r->stream)); // k_scan zeroes the ray-cast work counters in a full iteration
     if (doExtend) { launch_extend(p, r->travBlocks, stats, r->travMode, r->stream); if (ev) HIP_TRY(hipEventRecord(ev->e[4], r->stream)); }
-    if (doShadow) { launch_shadow(p, r->travBlocks, stats, r->travMode, r->stream); if (ev) HIP_TRY(hipEventRecord(ev->e[5], r->stream)); }
+    if (doShadow) { launch_shadow(p, r->travBlocks, stats, r->travMode, r->stream); if (ev && !extOnly) HIP_TRY(hipEventRecord(ev->e[5], r->stream)); }
     HIP_TRY(hipGetLastError());
     return GMUPT_OK;
 }
@@ -536,7 +539,7 @@ extern "C" int gmupt_enable_timing(gmupt_renderer* r, int enabled)
 {
     if (!r) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_enable_timing: null renderer");
     if (!enabled) { int rc = resolve_timing(r); if (rc != GMUPT_OK) return rc; }
-    r->timing = enabled != 0;
+    r->timing = enabled < 0 ? 0 : enabled;
     return GMUPT_OK;
 }
 

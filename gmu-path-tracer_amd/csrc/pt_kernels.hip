@@ -242,27 +242,35 @@ __global__ __launch_bounds__(kBlock) void k_logic(RenderParams p)
 // newPath.hlsl:55-60 (extension-queue offsets, shadow counter reset).
 __global__ __launch_bounds__(1024) void k_scan(RenderParams p, int clearFrame)
 {
-    __shared__ uint32_t s_part[1024];
+    __shared__ uint32_t s_wave[kNumCounts][16];
     __shared__ uint32_t s_total[kNumCounts];
-    const uint32_t t = threadIdx.x;
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint32_t chunk = (p.nBlocks + 1023u) / 1024u;
     const uint32_t lo = t * chunk, hi = (lo + chunk < p.nBlocks) ? lo + chunk : p.nBlocks;
+    uint32_t sum[kNumCounts], incl[kNumCounts];
+#pragma unroll
     for (int k = 0; k < kNumCounts; k++) {
-        uint32_t sum = 0;
-        for (uint32_t b = lo; b < hi; b++) sum += p.blockCounts[k * p.nBlocks + b];
-        s_part[t] = sum;
-        __syncthreads();
-        // Hillis-Steele inclusive scan over the 1024 partial sums
-        for (uint32_t off = 1; off < 1024; off <<= 1) {
-            uint32_t v = (t >= off) ? s_part[t - off] : 0u;
-            __syncthreads();
-            s_part[t] += v;
-            __syncthreads();
-        }
-        uint32_t run = s_part[t] - sum; // exclusive prefix of this thread's chunk
-        for (uint32_t b = lo; b < hi; b++) { uint32_t cnt = p.blockCounts[k * p.nBlocks + b]; p.blockOffsets[k * p.nBlocks + b] = run; run += cnt; }
-        if (t == 1023) s_total[k] = s_part[1023];
-        __syncthreads();
+        uint32_t s = 0;
+        for (uint32_t b = lo; b < hi; b++) s += p.blockCounts[k * p.nBlocks + b];
+        sum[k] = s;
+        // inclusive scan inside the wave64 by DPP-free shuffles, then across the 16 waves through LDS
+        uint32_t v = s;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t n = __shfl_up(v, off); if (lane >= (uint32_t)off) v += n; }
+        incl[k] = v;
+        if (lane == 63) s_wave[k][wave] = v;
+    }
+    __syncthreads();
+    if (t < kNumCounts) {
+        uint32_t run = 0;
+        for (int w = 0; w < 16; w++) { const uint32_t c = s_wave[t][w]; s_wave[t][w] = run; run += c; }
+        s_total[t] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kNumCounts; k++) {
+        uint32_t run = s_wave[k][wave] + incl[k] - sum[k]; // exclusive prefix of this thread's chunk
+        for (uint32_t b = lo; b < hi; b++) { const uint32_t cnt = p.blockCounts[k * p.nBlocks + b]; p.blockOffsets[k * p.nBlocks + b] = run; run += cnt; }
     }
     if (t == 0) {
         const uint32_t nUE4 = s_total[CLS_UE4], nGlass = s_total[CLS_GLASS], nEnded = s_total[CLS_ENDED];

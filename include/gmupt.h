@@ -160,7 +160,7 @@ typedef struct {
 } gmupt_stats;
 int gmupt_get_stats(gmupt_renderer* r, gmupt_stats* out); /* synchronises */
 int gmupt_reset_stats(gmupt_renderer* r);
-int gmupt_enable_timing(gmupt_renderer* r, int enabled); /* per-stage hipEvent timing (adds host work; off by default) */
+int gmupt_enable_timing(gmupt_renderer* r, int mode); /* hipEvent timing on the renderer's stream: 0 off (default), 1 every stage group, 2 only the extension ray cast */
 
 /* render until path_budget paths have completed (desc.path_budget must be > 0).  Every frame does what the reference's
  * Window::loop does (Source/Window.cpp:86-87): Camera::update (new randomSeed pair, iterationCounter++), upload, iterate.
