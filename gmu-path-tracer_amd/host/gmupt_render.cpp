@@ -16,6 +16,7 @@ int main(int argc, char** argv)
 	std::string scene = "cornell", dump;
 	unsigned w = WIDTH, h = HEIGHT, frames = 16, pool = PATHCOUNT, live = REFERENCE_LIVE_PATHS;
 	bool capture = false, buildOnly = false;
+	std::string paramsOnly;
 	for (int i = 1; i < argc; i++) {
 		const std::string a = argv[i];
 		auto next = [&]() -> const char* { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
@@ -27,10 +28,21 @@ int main(int argc, char** argv)
 		else if (a == "--dump") dump = next();
 		else if (a == "--capture") capture = true;
 		else if (a == "--build-only") buildOnly = true;
+		else if (a == "--params") paramsOnly = next();
 		else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
 	}
 	try
 	{
+		if (!paramsOnly.empty()) { // SceneParams: the per-scene CSV of the reference (Source/Scene.cpp:34-62)
+			const auto e = SceneParams::load(paramsOnly);
+			std::printf("{\"camera\": [%.9g, %.9g, %.9g, %.9g, %.9g], \"lights\": [", e.camera.position[0], e.camera.position[1], e.camera.position[2], e.camera.pitch, e.camera.yaw);
+			for (size_t i = 0; i < e.lights.size(); i++) {
+				const Light& l = e.lights[i];
+				std::printf("%s[%.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g]", i ? ", " : "", l.position[0], l.position[1], l.position[2], l.falloff, l.emission[0], l.emission[1], l.emission[2], l.radius);
+			}
+			std::printf("]}\n");
+			return 0;
+		}
 		if (buildOnly) { // host-only leg (BASELINE config 1): scene load + SBVH build + flatten, no GPU
 			const bool gltf = scene.size() > 5 && scene.compare(scene.size() - 5, 5, ".gltf") == 0;
 			const MeshData mesh = (scene == "cornell") ? MeshData::cornell() : gltf ? MeshData::loadGltf(scene) : MeshData::load(scene);

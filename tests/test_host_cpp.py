@@ -53,6 +53,22 @@ def test_gltf_loader_matches_written_mesh(exe, pkg, tmp_path):
     assert out2["triangles"] == 34
 
 
+def test_reference_params_files_parse(exe):
+    # the reference's own .params fixtures (Assets/Models/*/*.params, copied as data under tests/golden/reference_params)
+    d = os.path.join(ROOT, "tests", "golden", "reference_params")
+    box = json.loads(subprocess.run([exe, "--params", os.path.join(d, "box_box.params")], check=True, capture_output=True, text=True).stdout)
+    assert np.allclose(box["camera"], [-9.2, 0.4, -6.3, 2, 376]) and len(box["lights"]) == 1
+    assert np.allclose(box["lights"][0], [0, 4.5, 2.0, 100, 80, 80, 40, 0.5])
+    bg = json.loads(subprocess.run([exe, "--params", os.path.join(d, "bunny_glass_scene.params")], check=True, capture_output=True, text=True).stdout)
+    assert np.allclose(bg["camera"], [1.0, 3.0, 8.0, 0, 270]) and len(bg["lights"]) == 2 and np.allclose(bg["lights"][0][:3], [13.0, 4.5, 4.5])
+    for name in ("helmet_scene", "r3pu_scene", "bunny_glass_bunny_glass_closed"):
+        out = json.loads(subprocess.run([exe, "--params", os.path.join(d, name + ".params")], check=True, capture_output=True, text=True).stdout)
+        assert len(out["camera"]) == 5 and 1 <= len(out["lights"]) <= 2
+    # a missing file gives the defaults of Source/Scene.cpp:59-61
+    dflt = json.loads(subprocess.run([exe, "--params", "/nonexistent.params"], check=True, capture_output=True, text=True).stdout)
+    assert dflt["camera"] == [1, 3, 8, 0, 270] and len(dflt["lights"]) == 2
+
+
 def test_missing_scene_is_a_runtime_error(exe):
     r = subprocess.run([exe, "--build-only", "--scene", "/nonexistent/x.gmesh"], capture_output=True, text=True)
     assert r.returncode != 0 and "Non existing scene" in r.stderr            # wording of Source/Scene.cpp:79, exit path of main.cpp:19-23
