@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the counting replay that measures I and T")
     ap.add_argument("--no-stage-timing", action="store_true", help="do not record per-stage HIP events in the timed region")
-    ap.add_argument("--cpu-pool", type=int, default=1 << 15)
+    ap.add_argument("--cpu-pool", type=int, default=1 << 16)
     ap.add_argument("--cpu-iters", type=int, default=201)
     ap.add_argument("--cpu-prewarm", type=int, default=402)
     args = ap.parse_args()
@@ -161,7 +161,7 @@ def main():
                 traffic = json.load(open(pmc)).get("k_extend_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roofline = {"bound": "hbm", "kernel": "k_extend_d", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(per_launch), "avg_launch_ms": round(ext_ms, 4),
                     "rays_per_launch": s2.ext_rays / max(args.steps, 1),

@@ -597,6 +597,11 @@ extern "C" int gmupt_render_budget(gmupt_renderer* r, gmupt_camera* cam, uint32_
     *hostActive = 1;
     uint32_t k = 0;
     int rc = GMUPT_OK;
+    // Drain: stop when no slot is active any more -- or when the active count has not moved for 2048 iterations.  The reference
+    // has immortal paths: a NaN throughput survives `all(throughput <= 0)` and the Russian roulette test (logic.hlsl:237,251), and a
+    // path trapped inside closed geometry never meets a light, so a handful of slots can stay alive for ever (they just occupy pool
+    // slots in the reference's progressive loop).  2048 is ten times the ~201-bounce horizon of every healthy path.
+    uint32_t lastActive = 0xFFFFFFFFu, unchangedSince = 0;
     for (; k < max_iterations; k++) {
         cam->cam.update(0.0f);                       // Renderer::update -> Scene::update -> Camera::update (Renderer.cpp:158)
         rc = gmupt_set_camera(r, cam->cam.getBuffer());
@@ -607,6 +612,8 @@ extern "C" int gmupt_render_budget(gmupt_renderer* r, gmupt_camera* cam, uint32_
             if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
             if (e != hipSuccess) { rc = fail(GMUPT_ERR_HIP, "gmupt_render_budget: %s", hipGetErrorString(e)); break; }
             if (*hostActive == 0) { k++; break; }
+            if (*hostActive != lastActive) { lastActive = *hostActive; unchangedSince = k; }
+            else if (*hostActive < r->p.L && k - unchangedSince >= 2048u) { k++; break; } // only while draining (some slots already retired)
         }
     }
     (void)hipHostFree(hostActive);
