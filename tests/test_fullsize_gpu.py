@@ -57,3 +57,22 @@ def test_fullsize_properties_and_determinism(pkg, device, big_scene):
     assert np.nanmax(fa[..., :3]) <= 0.5 ** (1 / 2.2) + 1e-6 and not np.isnan(fa).any()
     assert st.reserved_ == 0
     a.close(); b.close(); sb.close()
+
+
+def test_bench_scene_long_run_bitwise(pkg, device, big_scene):
+    # the bench scene (259 372 triangles) at a pool the oracle can follow for two completion periods: deep paths, glass, metal,
+    # Russian roulette, the reference's immortal NaN paths -- everything the 64-spp render meets, bit for bit
+    Wm, Hm, Pm = 256, 144, 1 << 14
+    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, big_scene, Wm, Hm, Pm, threads=16)
+    for it in range(430):
+        PU.step_both(orc, hip, ocam, hcam)
+        if it % 107 == 106 or it == 429:
+            bad = PU.compare_state(orc, hip, Pm, Pm)
+            assert not bad, (it, bad[:3])
+            assert np.array_equal(orc.framebuffer().view(np.uint32), hip.framebuffer().view(np.uint32)), it
+    assert np.array_equal(orc.counters(), hip.counters())
+    so, sh = orc.stats(), hip.stats()
+    assert so.pathsEnded == sh.paths_completed > Pm and so.segments == sh.segments
+    pl = O.state_field(orc.path_state(), Pm, "pathLength")
+    assert int(pl.max()) > 150
+    hip.close(); sb.close(); orc.close()

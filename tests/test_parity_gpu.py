@@ -112,6 +112,25 @@ def test_edge_cases_odd_pool_single_triangle_and_no_geometry_hit(pkg, device):
     hip.close(); sb.close(); orc.close()
 
 
+def test_russian_roulette_branch_is_exercised(pkg, device, spheres_small_scene):
+    # closed room: paths live until the Russian roulette of logic.hlsl:248-255 (pathLength > 200) -- a rare branch with its own RNG draw
+    # that shifts the three draws of createShadowRay; run past it and require that it was really taken
+    W, H, P = 40, 24, 2048
+    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, spheres_small_scene, W, H, P)
+    seen_long = 0
+    for it in range(330):
+        PU.step_both(orc, hip, ocam, hcam)
+        if it >= 199 and it % 10 == 9:
+            pl = O.state_field(orc.path_state(), P, "pathLength")
+            seen_long = max(seen_long, int(pl.max()))
+        if it in (150, 205, 215, 260, 329):
+            _assert_same(orc, hip, P, P, it)
+    assert seen_long > 200, "no path reached the roulette threshold"
+    so, sh = orc.stats(), hip.stats()
+    assert so.pathsEnded == sh.paths_completed and so.pathsEnded > P, "every initial path must have ended (most of them by roulette)"
+    hip.close(); sb.close(); orc.close()
+
+
 def test_traversal_statistics_match(pkg, device, soup_scene):
     # the counting variant of the ray-cast kernels reports the same inner-node / triangle-test totals as the oracle for the
     # extension stage (the visited set does not depend on the traversal order)
