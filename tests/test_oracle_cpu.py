@@ -245,3 +245,115 @@ def test_textures_change_the_image(oracle, pkg):
     assert (st[:, 0] > 0).any(), "metallic must come from the texture's .x channel on some paths (quirk Q11)"
     assert not np.array_equal(a.framebuffer(), b.framebuffer())
     a.close(); b.close()
+
+
+def _craft(oracle, scene, P, W=16, H=16):
+    orc = oracle.Renderer(scene, W, H, P)
+    cam = oracle.Camera(W, H); cam.set_pose(*scene["camera"]); cam.update(); cam.update()
+    orc.set_camera(cam.buffer)
+    return orc, cam
+
+
+def test_primary_rays_follow_the_camera_model(oracle, cornell_scene):
+    # newPath.hlsl:33-39 against an independent float64 evaluation of the same pinhole model (+-1 pixel jitter, no half-pixel offset: Q2)
+    W, H, P = 64, 36, 4096
+    orc = oracle.Renderer(cornell_scene, W, H, P)
+    cam = oracle.Camera(W, H); cam.set_pose(*cornell_scene["camera"]); cam.update()
+    orc.set_camera(cam.buffer); orc.iterate()
+    st = orc.path_state(); cb = cam.buffer
+    d = oracle.state_field(st, P, "rayDirection").view(np.float32).astype(np.float64)
+    o = oracle.state_field(st, P, "rayOrigin").view(np.float32)
+    sc = oracle.state_field(st, P, "screenCoord").astype(np.float64)
+    assert np.all(o == np.array(cb.pos[:3], np.float32))
+    ulc, hor, ver = (np.array(v[:3], np.float64) for v in (cb.ulc, cb.horizontal, cb.vertical))
+    # d = normalize(ulc + u*hor - v*ver): solve for (u, v) by least squares and check they lie within one pixel of the pixel's corner
+    A = np.stack([hor, -ver], axis=1)
+    for k in range(0, P, 97):
+        # scale d so that its component along the view axis matches ulc's: the image plane is at distance 1 along -w
+        w_axis = np.cross(hor, ver); w_axis /= np.linalg.norm(w_axis)
+        tscale = np.dot(ulc, w_axis) / np.dot(d[k], w_axis)
+        uv, *_ = np.linalg.lstsq(A, d[k] * tscale - ulc, rcond=None)
+        px, py = uv[0] * W, uv[1] * H
+        assert abs(px - sc[k, 0]) <= 1.0 + 1e-3 and abs(py - sc[k, 1]) <= 1.0 + 1e-3, (k, px, py, sc[k])
+    assert np.allclose(np.linalg.norm(d, axis=1), 1.0, atol=1e-6)
+    orc.close()
+
+
+def test_light_spheres_are_hit_analytically(oracle, cornell_scene):
+    # rayLightIntersection (extensionRayCast.hlsl:168-194): rays aimed at a light centre from open space hit it at |c - o| - radius
+    P = 256
+    orc, cam = _craft(oracle, cornell_scene, P)
+    L = cornell_scene["lights"][1]; c = np.array(L["position"], np.float64); rad = float(L["radius"])
+    rng = np.random.default_rng(1)
+    o = (c + rng.normal(size=(P, 3)) * 0.2 + np.array([0.0, 0.0, 2.5])).astype(np.float32)   # in front of the light, inside the room
+    d = c - o.astype(np.float64); dist = np.linalg.norm(d, axis=1); d = (d / dist[:, None]).astype(np.float32)
+    w = orc.path_state().view(np.float32)
+    w[0:4 * P].reshape(P, 4)[:, :3] = o; w[4 * P:8 * P].reshape(P, 4)[:, :3] = d
+    orc.queues()[3][:] = np.arange(P, dtype=np.uint32)
+    orc.stage("extension")
+    st = orc.path_state()
+    hit = oracle.state_field(st, P, "hitDistance").view(np.float32)[:, 0]
+    em = oracle.state_field(st, P, "isEmitter")[:, 0]
+    assert np.all(em == 2), "light slot 1 -> isEmitter = index + 1"
+    assert np.allclose(hit, dist - rad, atol=2e-5)
+    orc.close()
+
+
+def test_ue4_diffuse_lobe_is_cosine_distributed(oracle, pkg):
+    # materialUE4.hlsl:40-48 with metallic = 0: direction = cosine-weighted hemisphere sample around the shading normal, so E[cos] = 2/3 and
+    # lightThroughput = eval * cos / pdf = (base/pi + spec) * cos / (cos/pi) ~ base colour for a rough dielectric seen head-on
+    scene = pkg.scenes.build_scene(pkg.scenes.cornell_mesh())
+    P = 8192
+    orc, cam = _craft(oracle, scene, P)
+    w = orc.path_state().view(np.float32)
+    n = np.array([0.0, 1.0, 0.0], np.float32)
+    w[4 * P:8 * P].reshape(P, 4)[:, :3] = np.array([0.0, -1.0, 0.0], np.float32)        # rayDirection: straight down onto the floor
+    w[14 * P:18 * P].reshape(P, 4)[:, :3] = n                                            # normal (offset 56 bytes = 14 words per path)
+    w[8 * P:12 * P].reshape(P, 4)[:, :3] = np.array([0.5, 0.6, 0.7], np.float32)         # matColor
+    w[12 * P:14 * P].reshape(P, 2)[:] = np.array([0.0, 1.0], np.float32)                 # metallic 0, roughness 1
+    w[35 * P:39 * P].reshape(P, 4)[:, :3] = np.array([0.0, -1.0, 0.0], np.float32)       # shadowrayDirection below the surface: no NEE push
+    orc.queues()[1][:] = np.arange(P, dtype=np.uint32)
+    qc = orc.counters(); qc[2] = P; qc[4] = 0; qc[6] = 0
+    orc.stage("material_ue4")
+    st = orc.path_state()
+    d = oracle.state_field(st, P, "rayDirection").view(np.float32).astype(np.float64)
+    cos = d @ n.astype(np.float64)
+    assert np.all(cos >= -1e-6) and abs(cos.mean() - 2.0 / 3.0) < 0.01 and abs((d[:, 0] ** 2).mean() - 0.25) < 0.01
+    lt = oracle.state_field(st, P, "lightThroughput").view(np.float32)
+    ok = cos > 0.05
+    # diffuse term alone gives exactly the base colour; the small GGX specular of a roughness-1 dielectric adds a few percent
+    assert np.all(lt[ok] >= np.array([0.5, 0.6, 0.7]) - 1e-4) and np.median(lt[ok], axis=0)[0] < 0.5 * 1.25
+    assert orc.counters()[6] == 0
+    orc.close()
+
+
+def test_glass_refraction_obeys_snell(oracle, pkg):
+    # materialGlass.hlsl:23-46: entering glass (n = 1.458) a transmitted ray satisfies sin(t) = sin(i) / 1.458 and stays in the plane of
+    # incidence; with the reference's Schlick term (r0 - (1 - r0) m^5 <= 0.035, quirk Q12) almost every ray is transmitted
+    scene = pkg.scenes.build_scene(pkg.scenes.cornell_mesh())
+    P = 4096
+    orc, cam = _craft(oracle, scene, P)
+    rng = np.random.default_rng(2)
+    n = np.array([0.0, 0.0, 1.0])
+    ang = rng.uniform(0.05, 1.3, P); phi = rng.uniform(0, 2 * np.pi, P)
+    din = np.stack([np.sin(ang) * np.cos(phi), np.sin(ang) * np.sin(phi), -np.cos(ang)], axis=1).astype(np.float32)   # heading into -z, normal +z
+    w = orc.path_state().view(np.float32)
+    w[4 * P:8 * P].reshape(P, 4)[:, :3] = din
+    w[14 * P:18 * P].reshape(P, 4)[:, :3] = n.astype(np.float32)
+    w[8 * P:12 * P].reshape(P, 4)[:, :3] = np.array([0.9, 0.95, 1.0], np.float32)
+    orc.queues()[2][:] = np.arange(P, dtype=np.uint32)
+    qc = orc.counters(); qc[3] = P; qc[5] = 0
+    orc.stage("material_glass")
+    st = orc.path_state()
+    dout = oracle.state_field(st, P, "rayDirection").view(np.float32).astype(np.float64)
+    transmitted = dout[:, 2] < 0
+    assert transmitted.mean() > 0.9
+    sin_i = np.sin(ang)[transmitted]; sin_t = np.linalg.norm(dout[transmitted][:, :2], axis=1)
+    assert np.allclose(sin_t, sin_i / 1.458, atol=2e-6)
+    azi_in = np.arctan2(din[transmitted][:, 1], din[transmitted][:, 0]); azi_out = np.arctan2(dout[transmitted][:, 1], dout[transmitted][:, 0])
+    assert np.allclose(np.cos(azi_in - azi_out), 1.0, atol=1e-5)
+    refl = ~transmitted
+    assert np.allclose(dout[refl][:, 2], -din[refl][:, 2].astype(np.float64), atol=1e-6)        # mirror reflection for the few reflected ones
+    lt = oracle.state_field(st, P, "lightThroughput").view(np.float32)
+    assert np.all(lt == np.array([0.9, 0.95, 1.0], np.float32))                                  # throughput = base colour (:75)
+    orc.close()
