@@ -53,17 +53,24 @@ def test_gltf_loader_matches_written_mesh(exe, pkg, tmp_path):
     assert out2["triangles"] == 34
 
 
-def test_reference_params_files_parse(exe):
-    # the reference's own .params fixtures (Assets/Models/*/*.params, copied as data under tests/golden/reference_params)
-    d = os.path.join(ROOT, "tests", "golden", "reference_params")
-    box = json.loads(subprocess.run([exe, "--params", os.path.join(d, "box_box.params")], check=True, capture_output=True, text=True).stdout)
+def test_reference_params_files_parse(exe, tmp_path):
+    # the values of the reference's own .params data files (tests/golden/reference_params.json), written back as CSV and parsed by
+    # SceneParams::load (Source/Scene.cpp:34-55)
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_params.json")))["scenes"]
+    def run(name):
+        path = str(tmp_path / (name + ".params"))
+        with open(path, "w") as f:
+            rows = [ref[name]["camera_xyz_pitch_yaw"]] + ref[name]["lights_xyz_falloff_rgb_radius"]
+            f.write("\n".join(", ".join("%g" % v for v in row) for row in rows))       # no trailing newline, like the originals
+        return json.loads(subprocess.run([exe, "--params", path], check=True, capture_output=True, text=True).stdout)
+    box = run("box_box")
     assert np.allclose(box["camera"], [-9.2, 0.4, -6.3, 2, 376]) and len(box["lights"]) == 1
     assert np.allclose(box["lights"][0], [0, 4.5, 2.0, 100, 80, 80, 40, 0.5])
-    bg = json.loads(subprocess.run([exe, "--params", os.path.join(d, "bunny_glass_scene.params")], check=True, capture_output=True, text=True).stdout)
+    bg = run("bunny_glass_scene")
     assert np.allclose(bg["camera"], [1.0, 3.0, 8.0, 0, 270]) and len(bg["lights"]) == 2 and np.allclose(bg["lights"][0][:3], [13.0, 4.5, 4.5])
-    for name in ("helmet_scene", "r3pu_scene", "bunny_glass_bunny_glass_closed"):
-        out = json.loads(subprocess.run([exe, "--params", os.path.join(d, name + ".params")], check=True, capture_output=True, text=True).stdout)
-        assert len(out["camera"]) == 5 and 1 <= len(out["lights"]) <= 2
+    for name in ref:
+        out = run(name)
+        assert np.allclose(out["camera"], ref[name]["camera_xyz_pitch_yaw"]) and np.allclose(out["lights"], ref[name]["lights_xyz_falloff_rgb_radius"])
     # a missing file gives the defaults of Source/Scene.cpp:59-61
     dflt = json.loads(subprocess.run([exe, "--params", "/nonexistent.params"], check=True, capture_output=True, text=True).stdout)
     assert dflt["camera"] == [1, 3, 8, 0, 270] and len(dflt["lights"]) == 2
