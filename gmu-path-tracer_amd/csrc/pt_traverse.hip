@@ -202,6 +202,13 @@ __global__ __launch_bounds__(kDefBlock) void k_extend_d(RenderParams p)
             next = (next + (uint32_t)nIdle < end) ? next + (uint32_t)nIdle : end;
         }
 
+        if (STATS) { // lane census (collect_stats only): where do the 64 lanes of a wave spend the loop iterations?
+            const bool pendingNow = (qCount > 0) || (ti >= 0);
+            const uint32_t nI = __popcll(__ballot(cur == kDone && !pendingNow)), nW = __popcll(__ballot(cur >= 0));
+            const uint32_t nS = __popcll(__ballot(cur < 0 && cur != kDone)), nP = __popcll(__ballot(cur == kDone && pendingNow));
+            if ((threadIdx.x & 63) == 0) { atomicAdd(&p.stats->extDepthHist[28], (unsigned long long)nI); atomicAdd(&p.stats->extDepthHist[29], (unsigned long long)nW);
+                                           atomicAdd(&p.stats->extDepthHist[30], (unsigned long long)nS); atomicAdd(&p.stats->extDepthHist[31], (unsigned long long)nP); }
+        }
         // ---- walk: REPS inner steps per lane; a reached leaf is queued and the walk goes on with the popped node
 #pragma unroll
         for (int rep = 0; rep < REPS; rep++) {
