@@ -15,7 +15,7 @@ completes paths in bursts with a period of 201 iterations (damping 0.55 per peri
 With N GPUs the frame is split into N row bands (one private pipeline per rank, no data-path collective); the timed region
 ends with the RCCL gather of the tiles to rank 0.
 
-Prints ONE JSON line on rank 0 (see the task contract); `roofline` is for the dominant kernel (extension ray cast) and
+Prints ONE JSON line on rank 0 (see the task contract); `roofline` is for the dominant kernel (the ray-cast launch: extension + shadow rays in one persistent kernel) and
 `cpu_baseline` is the scalar CPU oracle timed on a bounded sample on this box (rank 0, N = 1 only).
 """
 import argparse
@@ -35,6 +35,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 def ext_bytes(rays, inner, tris, lights):
     """Algorithmic bytes of the extension ray cast: 4 + 24 + 48(1 + 2I) + 52T + 32L + 48 per ray."""
     return rays * (4 + 24 + 48 + 32 * lights + 48) + 96 * inner + 52 * tris
+
+
+def shadow_bytes(rays, inner, tris):
+    """Algorithmic bytes of the shadow ray cast: 4 + 24 + 4 + 48(1 + 2I) + 52T + 4 per ray."""
+    return rays * (4 + 24 + 4 + 48 + 4) + 96 * inner + 52 * tris
 
 
 def main():
@@ -152,19 +157,25 @@ def main():
         s2 = r2.stats()
         r2.close()
         nbytes = ext_bytes(s2.ext_rays, s2.ext_inner, s2.ext_tris, scene["light_count"])
+        fused = bool(s2.flags & capi.STAT_FUSED_CAST)   # one launch casts the extension AND the shadow rays: its bytes are the sum
+        if fused:
+            nbytes += shadow_bytes(s2.sh_rays, s2.sh_inner, s2.sh_tris)
+        kname = "k_cast_m" if fused else "k_extend_d"
         per_launch = nbytes / max(args.steps, 1)
         achieved = per_launch / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("k_extend_hbm_bytes_per_launch")
+                traffic = json.load(open(pmc)).get(kname + "_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "k_extend_d", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(per_launch), "avg_launch_ms": round(ext_ms, 4),
-                    "rays_per_launch": s2.ext_rays / max(args.steps, 1),
+                    "rays_per_launch": (s2.ext_rays + (s2.sh_rays if fused else 0)) / max(args.steps, 1),
+                    "shadow_rays_per_launch": s2.sh_rays / max(args.steps, 1), "shadow_inner_per_ray": round(s2.sh_inner / max(s2.sh_rays, 1), 2),
+                    "shadow_tris_per_ray": round(s2.sh_tris / max(s2.sh_rays, 1), 2),
                     "inner_per_ray": round(s2.ext_inner / max(s2.ext_rays, 1), 2), "tris_per_ray": round(s2.ext_tris / max(s2.ext_rays, 1), 2),
                     "simd_efficiency": {"inner": round(s2.ext_inner / max(64 * s2.ext_wave_inner, 1), 3), "triangles": round(s2.ext_tris / max(64 * s2.ext_wave_tris, 1), 3),
                                         "shadow_inner": round(s2.sh_inner / max(64 * s2.sh_wave_inner, 1), 3), "shadow_triangles": round(s2.sh_tris / max(64 * s2.sh_wave_tris, 1), 3)}}

@@ -47,9 +47,12 @@ class RendererDesc(C.Structure):
                 ("path_budget", C.c_uint32), ("max_depth", C.c_uint32), ("collect_stats", C.c_uint32)]
 
 
+STAT_STACK_OVERFLOW, STAT_FUSED_CAST = 1, 2
+
+
 class Stats(C.Structure):
     _fields_ = [("iterations", C.c_uint64), ("paths_generated", C.c_uint64), ("paths_completed", C.c_uint64),
-                ("segments", C.c_uint64), ("active_paths", C.c_uint32), ("reserved_", C.c_uint32),
+                ("segments", C.c_uint64), ("active_paths", C.c_uint32), ("flags", C.c_uint32),
                 ("ext_rays", C.c_uint64), ("ext_inner", C.c_uint64), ("ext_leaves", C.c_uint64), ("ext_tris", C.c_uint64),
                 ("sh_rays", C.c_uint64), ("sh_inner", C.c_uint64), ("sh_leaves", C.c_uint64), ("sh_tris", C.c_uint64),
                 ("ms_logic", C.c_double), ("ms_scan", C.c_double), ("ms_accumulate", C.c_double), ("ms_material", C.c_double),

@@ -34,6 +34,8 @@ void launch_scan(const RenderParams& p, int clearFrame, hipStream_t s);
 void launch_material(const RenderParams& p, int clearFrame, hipStream_t s);
 void launch_extend(const RenderParams& p, uint32_t blocks, bool stats, int mode, hipStream_t s);
 void launch_shadow(const RenderParams& p, uint32_t blocks, bool stats, int mode, hipStream_t s);
+void launch_cast(const RenderParams& p, bool stats, int mode, hipStream_t s);
+bool traversal_is_fused(int mode);
 void launch_detmath(int fn, const float* x, const float* y, float* out, uint32_t n, hipStream_t s);
 uint32_t traversal_block_threads();
 uint32_t deferred_block_threads();
@@ -213,6 +215,23 @@ extern "C" void gmupt_renderer_destroy(gmupt_renderer* r)
     delete r;
 }
 
+// GMUPT_TRAVERSAL selects a rung of the traversal ladder; all rungs give identical results, the default is the fastest
+static int parse_traversal_mode(const char* tv)
+{
+    constexpr int kDefault = 60;                                            // cast0: both ray casts in one mixed-lane persistent launch
+    if (!tv || !*tv) return kDefault;
+    if (std::strcmp(tv, "whilewhile") == 0) return 0;
+    if (std::strcmp(tv, "ref") == 0) return 1;
+    if (std::strcmp(tv, "static") == 0) return 2;
+    if (std::strncmp(tv, "ifif", 4) == 0) return 3 + std::atoi(tv + 4);
+    if (std::strcmp(tv, "coop") == 0) return 20;
+    if (std::strcmp(tv, "top") == 0) return 30;
+    if (std::strncmp(tv, "def", 3) == 0) return 40 + std::atoi(tv + 3);     // separate deferred-leaf launches
+    if (std::strncmp(tv, "pipe", 4) == 0) return 50 + std::atoi(tv + 4);    // three-slot lane pipeline
+    if (std::strncmp(tv, "cast", 4) == 0) return 60 + std::atoi(tv + 4);    // cast0 mixed lanes, cast1 extension then shadow per wave
+    return kDefault;
+}
+
 extern "C" int gmupt_renderer_create(gmupt_device* dev, const gmupt_renderer_desc* desc, gmupt_renderer** out)
 {
     if (!dev || !desc || !out) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_renderer_create: null argument");
@@ -221,7 +240,7 @@ extern "C" int gmupt_renderer_create(gmupt_device* dev, const gmupt_renderer_des
     gmupt_renderer* r = new (std::nothrow) gmupt_renderer();
     if (!r) return fail(GMUPT_ERR_OUT_OF_MEMORY, "gmupt_renderer_create: out of host memory");
     r->dev = dev; r->desc = *desc;
-    { const char* tv = std::getenv("GMUPT_TRAVERSAL"); r->travMode = !tv ? 40 : (std::strcmp(tv, "ref") == 0 ? 1 : (std::strcmp(tv, "static") == 0 ? 2 : (std::strncmp(tv, "ifif", 4) == 0 ? 3 + std::atoi(tv + 4) : (std::strcmp(tv, "whilewhile") == 0 ? 0 : (std::strcmp(tv, "coop") == 0 ? 20 : (std::strcmp(tv, "top") == 0 ? 30 : (std::strncmp(tv, "def", 3) == 0 ? 40 + std::atoi(tv + 3) : 40))))))); }
+    r->travMode = parse_traversal_mode(std::getenv("GMUPT_TRAVERSAL"));
     if (r->desc.pool_paths == 0) r->desc.pool_paths = GMUPT_PATHCOUNT;
     if (r->desc.live_paths == 0 || r->desc.live_paths > r->desc.pool_paths) r->desc.live_paths = r->desc.pool_paths;
     const uint32_t P = r->desc.pool_paths, L = r->desc.live_paths;
@@ -460,6 +479,14 @@ static int run_iteration(gmupt_renderer* r, bool doShade, bool doExtend, bool do
         if (ev) HIP_TRY(hipEventRecord(ev->e[3], r->stream));
     }
     if (!doShade) HIP_TRY(hipMemsetAsync(p.travCounters, 0, 16, r->stream)); // k_scan zeroes the ray-cast work counters in a full iteration
+    if (doExtend && doShadow && traversal_is_fused(r->travMode)) {
+        // one launch for both ray casts; its time is reported as the extension stage, the shadow stage as zero
+        launch_cast(p, stats, r->travMode, r->stream);
+        if (ev) HIP_TRY(hipEventRecord(ev->e[4], r->stream));
+        if (ev && !extOnly) HIP_TRY(hipEventRecord(ev->e[5], r->stream));
+        HIP_TRY(hipGetLastError());
+        return GMUPT_OK;
+    }
     if (doExtend) { launch_extend(p, r->travBlocks, stats, r->travMode, r->stream); if (ev) HIP_TRY(hipEventRecord(ev->e[4], r->stream)); }
     if (doShadow) { launch_shadow(p, r->travBlocks, stats, r->travMode, r->stream); if (ev && !extOnly) HIP_TRY(hipEventRecord(ev->e[5], r->stream)); }
     HIP_TRY(hipGetLastError());
@@ -555,7 +582,7 @@ extern "C" int gmupt_get_stats(gmupt_renderer* r, gmupt_stats* out)
     std::memset(out, 0, sizeof(*out));
     out->iterations = r->iterations;
     out->paths_generated = ds.pathsGenerated; out->paths_completed = ds.pathsCompleted; out->segments = ds.segments;
-    out->active_paths = ds.activePaths; out->reserved_ = ds.stackOverflow;
+    out->active_paths = ds.activePaths; out->flags = (ds.stackOverflow ? GMUPT_STAT_STACK_OVERFLOW : 0u) | (traversal_is_fused(r->travMode) ? GMUPT_STAT_FUSED_CAST : 0u);
     out->ext_rays = ds.extRays; out->ext_inner = ds.extInner; out->ext_leaves = ds.extLeaves; out->ext_tris = ds.extTris;
     out->sh_rays = ds.shRays; out->sh_inner = ds.shInner; out->sh_leaves = ds.shLeaves; out->sh_tris = ds.shTris;
     out->ms_logic = r->msStage[0]; out->ms_scan = r->msStage[1]; out->ms_material = r->msStage[2];

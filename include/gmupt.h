@@ -141,13 +141,15 @@ int gmupt_copy_framebuffer_to_device(gmupt_renderer* r, void* device_dst, size_t
 int gmupt_get_counters(gmupt_renderer* r, uint32_t out[8]);
 int gmupt_synchronize(gmupt_renderer* r);
 
+#define GMUPT_STAT_STACK_OVERFLOW 1u /* a traversal stack exceeded 64 entries (results invalid; never seen on a builder-made tree) */
+#define GMUPT_STAT_FUSED_CAST 2u     /* both ray casts run as one launch: ms_extend is the time of that launch, ms_shadow is 0 */
 typedef struct {
     uint64_t iterations;
     uint64_t paths_generated;    /* new paths started (device counter) */
     uint64_t paths_completed;    /* paths accumulated into the framebuffer */
     uint64_t segments;           /* live-slot iterations (the reference overlay's "MP/s" unit, GUI.cpp:48) */
     uint32_t active_paths;       /* slots not retired by path_budget */
-    uint32_t reserved_;
+    uint32_t flags;              /* GMUPT_STAT_* bits */
     /* collect_stats only */
     uint64_t ext_rays, ext_inner, ext_leaves, ext_tris;
     uint64_t sh_rays, sh_inner, sh_leaves, sh_tris;

@@ -19,5 +19,5 @@ st = r.stats()
 out = {"config": "config5", "triangles": int(mesh["indices"].shape[0]), "nodes": int(scene["nodes"].shape[0]), "depth": scene["depth"], "build_s": round(build_s, 1),
        "ms_per_step": round(dt / 40 * 1e3, 3), "mpaths_per_s": round(st.paths_completed / dt / 1e6, 2), "msegments_per_s": round(st.segments / dt / 1e6, 1),
        "stage_ms": {k: round(getattr(st, "ms_" + k) / st.timed_iterations, 3) for k in ("logic", "scan", "material", "extend", "shadow")},
-       "stack_overflow": st.reserved_}
+       "stack_overflow": (st.flags & 1)}
 print(json.dumps(out), flush=True)

@@ -31,9 +31,10 @@ def main(fetch_dir, write_dir, out, skip=265):
         f = fetch.get(k, (0.0, 0))[0] * 1024.0
         w = write.get(k, (0.0, 0))[0] * 1024.0
         res["kernels"][k] = {"fetch_bytes_raw": int(f), "fetch_bytes_x2": int(2 * f), "write_bytes": int(w), "dispatches": fetch.get(k, (0, 0))[1]}
-        if "k_extend" in k:
-            res["k_extend_hbm_bytes_per_launch"] = int(2 * f + w)
-            res["k_extend_hbm_bytes_per_launch_raw"] = int(f + w)
+        for short in ("k_extend_d", "k_shadow_d", "k_cast_m", "k_cast_d"):   # the keys bench.py reads for roofline.traffic
+            if short in k:
+                res[short + "_hbm_bytes_per_launch"] = int(2 * f + w)
+                res[short + "_hbm_bytes_per_launch_raw"] = int(f + w)
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
