@@ -57,10 +57,12 @@ class Stats(C.Structure):
                 ("sh_rays", C.c_uint64), ("sh_inner", C.c_uint64), ("sh_leaves", C.c_uint64), ("sh_tris", C.c_uint64),
                 ("ms_logic", C.c_double), ("ms_scan", C.c_double), ("ms_accumulate", C.c_double), ("ms_material", C.c_double),
                 ("ms_extend", C.c_double), ("ms_shadow", C.c_double), ("timed_iterations", C.c_uint64),
-                ("ext_wave_inner", C.c_uint64), ("ext_wave_tris", C.c_uint64), ("sh_wave_inner", C.c_uint64), ("sh_wave_tris", C.c_uint64), ("ext_depth_hist", C.c_uint64 * 32)]
+                ("ext_wave_inner", C.c_uint64), ("ext_wave_tris", C.c_uint64), ("sh_wave_inner", C.c_uint64), ("sh_wave_tris", C.c_uint64), ("ext_depth_hist", C.c_uint64 * 32),
+                ("lane_census", C.c_uint64 * 4), ("cast_waves", C.c_uint64), ("cast_wave_ticks", C.c_uint64), ("cast_wave_ticks_max", C.c_uint64),
+                ("cast_wave_end_hist", C.c_uint64 * 32), ("ray_inner_hist", C.c_uint64 * 32)]
 
     def as_dict(self):
-        return {n: (list(getattr(self, n)) if n == "ext_depth_hist" else getattr(self, n)) for n, _ in self._fields_}
+        return {n: (list(getattr(self, n)) if hasattr(getattr(self, n), "__len__") else getattr(self, n)) for n, _ in self._fields_}
 
 
 class SbvhParams(C.Structure):
@@ -84,6 +86,10 @@ SYMBOLS = {
     "gmupt_buffer_destroy": (None, [_P]),
     "gmupt_buffer_size": (C.c_size_t, [_P]),
     "gmupt_texture_array_create": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+    "gmupt_image_decode_png": (C.c_int, [_P, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(_P)]),
+    "gmupt_image_free": (None, [_P]),
+    "gmupt_image_resize_square": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
+    "gmupt_texture_common_size": (C.c_uint32, [C.POINTER(C.c_size_t), C.c_uint32]),
     "gmupt_renderer_create": (C.c_int, [_P, C.POINTER(RendererDesc), C.POINTER(_P)]),
     "gmupt_renderer_destroy": (None, [_P]),
     "gmupt_renderer_bind_scene": (C.c_int, [_P] * 7),
@@ -120,6 +126,7 @@ SYMBOLS = {
     "gmupt_camera_update_resolution": (None, [_P, C.c_uint32, C.c_uint32]),
     "gmupt_camera_set_pose": (None, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
     "gmupt_camera_update": (None, [_P, C.c_float]),
+    "gmupt_camera_set_input": (None, [_P, C.c_float, C.c_float, C.c_uint32]),
     "gmupt_camera_reset_accumulation": (None, [_P]),
     "gmupt_camera_get_buffer": (C.POINTER(CameraBuffer), [_P]),
     "gmupt_version": (C.c_char_p, []),
@@ -203,6 +210,43 @@ class TextureArray:
             self.h = _P()
 
 
+def decode_png(data):
+    """PNG file bytes -> (h, w, 4) uint8 through gmupt_image_decode_png (the reference's lodepng::decode call, Scene.cpp:226)."""
+    w, h, mem = C.c_uint32(), C.c_uint32(), _P()
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(bytes(data))
+    _check(lib().gmupt_image_decode_png(buf, len(data), C.byref(w), C.byref(h), C.byref(mem)))
+    try:
+        out = np.ctypeslib.as_array(C.cast(mem, C.POINTER(C.c_uint8)), shape=(h.value, w.value, 4)).copy()
+    finally:
+        lib().gmupt_image_free(mem)
+    return out
+
+
+def resize_square(rgba, new_size):
+    """Square RGBA8 resize (the reference's avir call, Scene.cpp:276-279; own Lanczos-3 filter)."""
+    rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+    assert rgba.ndim == 3 and rgba.shape[0] == rgba.shape[1] and rgba.shape[2] == 4
+    out = np.empty((new_size, new_size, 4), dtype=np.uint8)
+    _check(lib().gmupt_image_resize_square(_ptr(rgba), rgba.shape[0], new_size, _ptr(out)))
+    return out
+
+
+def texture_common_size(layer_bytes):
+    arr = (C.c_size_t * len(layer_bytes))(*layer_bytes)
+    return int(lib().gmupt_texture_common_size(arr, len(layer_bytes)))
+
+
+def texture_array_from_png(files):
+    """Layers from encoded PNG files in material order, as Scene::loadSpecificTexture + createTextures: decode, pick the common size by
+    the median rule, resize the layers that differ.  Returns (layers, size, size, 4) uint8."""
+    layers = [decode_png(f) for f in files]
+    for l in layers:
+        if l.shape[0] != l.shape[1]:
+            raise GmuptError("texture is not square")
+    size = texture_common_size([l.size for l in layers])
+    return np.stack([l if l.shape[0] == size else resize_square(l, size) for l in layers])
+
+
 class SceneBuffers:
     """The six scene resources of Renderer::draw (t0-t4, b1) uploaded through gmupt_buffer_create."""
 
@@ -240,8 +284,14 @@ class Camera:
     def update(self, dt=0.0):
         lib().gmupt_camera_update(self.h, dt)
 
+    def update_resolution(self, width, height):
+        lib().gmupt_camera_update_resolution(self.h, width, height)
+
     def reset_accumulation(self):
         lib().gmupt_camera_reset_accumulation(self.h)
+
+    def set_input(self, mouse_dx=0.0, mouse_dy=0.0, w=False, s=False, a=False, d=False):
+        lib().gmupt_camera_set_input(self.h, mouse_dx, mouse_dy, (1 if w else 0) | (2 if s else 0) | (4 if a else 0) | (8 if d else 0))
 
     @property
     def buffer(self):

@@ -3,6 +3,8 @@
 #include "pt_device.hpp"
 #include "../host/sbvh_builder.hpp"
 #include "../host/Camera.hpp"
+#include "../host/TextureLoader.hpp"
+#include "../host/png_reader.hpp"
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -126,6 +128,38 @@ extern "C" int gmupt_buffer_create(gmupt_device* dev, gmupt_buffer_kind kind, co
     if (e != hipSuccess) { if (b->dptr) (void)hipFree(b->dptr); delete b; return fail(GMUPT_ERR_HIP, "gmupt_buffer_create(%zu bytes): %s", alloc, hipGetErrorString(e)); }
     *out = b;
     return GMUPT_OK;
+}
+
+extern "C" int gmupt_image_decode_png(const void* png, size_t bytes, uint32_t* width, uint32_t* height, uint8_t** rgba)
+{
+    if (!png || !width || !height || !rgba) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_image_decode_png: null argument");
+    *rgba = nullptr; *width = *height = 0;
+    try {
+        gmupt::png::Image img = gmupt::png::decode(static_cast<const uint8_t*>(png), bytes);
+        uint8_t* mem = static_cast<uint8_t*>(std::malloc(img.rgba.size()));
+        if (!mem) return fail(GMUPT_ERR_OUT_OF_MEMORY, "gmupt_image_decode_png: out of host memory");
+        std::memcpy(mem, img.rgba.data(), img.rgba.size());
+        *rgba = mem; *width = img.width; *height = img.height;
+    } catch (const std::exception& e) { return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_image_decode_png: %s", e.what()); }
+    return GMUPT_OK;
+}
+
+extern "C" void gmupt_image_free(uint8_t* rgba) { std::free(rgba); }
+
+extern "C" int gmupt_image_resize_square(const uint8_t* rgba, uint32_t old_size, uint32_t new_size, uint8_t* dst)
+{
+    if (!rgba || !dst || old_size == 0 || new_size == 0) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_image_resize_square: null or empty argument");
+    try {
+        const std::vector<uint8_t> out = gmupt::resizeSquare(rgba, old_size, new_size);
+        std::memcpy(dst, out.data(), out.size());
+    } catch (const std::exception& e) { return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_image_resize_square: %s", e.what()); }
+    return GMUPT_OK;
+}
+
+extern "C" uint32_t gmupt_texture_common_size(const size_t* layer_bytes, uint32_t layers)
+{
+    if (!layer_bytes || layers == 0) return 0;
+    return gmupt::commonDimension(std::vector<size_t>(layer_bytes, layer_bytes + layers));
 }
 
 extern "C" int gmupt_texture_array_create(gmupt_device* dev, const uint8_t* rgba8, uint32_t size, uint32_t layers, gmupt_buffer** out)
@@ -589,7 +623,9 @@ extern "C" int gmupt_get_stats(gmupt_renderer* r, gmupt_stats* out)
     out->ms_accumulate = 0.0; // accumulation is fused into the material kernel
     out->ms_extend = r->msStage[3]; out->ms_shadow = r->msStage[4];
     out->timed_iterations = r->timedIters;
-    for (int k = 0; k < 32; k++) out->ext_depth_hist[k] = ds.extDepthHist[k];
+    for (int k = 0; k < 32; k++) { out->ext_depth_hist[k] = ds.extDepthHist[k]; out->cast_wave_end_hist[k] = ds.castWaveEndHist[k]; out->ray_inner_hist[k] = ds.rayInnerHist[k]; }
+    for (int k = 0; k < 4; k++) out->lane_census[k] = ds.laneCensus[k];
+    out->cast_waves = ds.castWaves; out->cast_wave_ticks = ds.castWaveClocks; out->cast_wave_ticks_max = ds.castWaveClocksMax;
     out->ext_wave_inner = ds.extWaveInner; out->ext_wave_tris = ds.extWaveTris; out->sh_wave_inner = ds.shWaveInner; out->sh_wave_tris = ds.shWaveTris;
     return GMUPT_OK;
 }
@@ -806,5 +842,12 @@ extern "C" void gmupt_camera_destroy(gmupt_camera* c) { delete c; }
 extern "C" void gmupt_camera_update_resolution(gmupt_camera* c, uint32_t width, uint32_t height) { if (c) c->cam.updateResolution(width, height); }
 extern "C" void gmupt_camera_set_pose(gmupt_camera* c, float x, float y, float z, float pitch, float yaw) { if (c) { c->cam.setPosition(x, y, z); c->cam.setRotation(pitch, yaw); } }
 extern "C" void gmupt_camera_update(gmupt_camera* c, float dt) { if (c) c->cam.update(dt); }
+extern "C" void gmupt_camera_set_input(gmupt_camera* c, float mouse_dx, float mouse_dy, uint32_t keys_wsad)
+{
+    if (!c) return;
+    c->cam.addMouseDelta(mouse_dx, mouse_dy);
+    c->cam.setKeys((keys_wsad & 1u) != 0, (keys_wsad & 2u) != 0, (keys_wsad & 4u) != 0, (keys_wsad & 8u) != 0);
+}
+
 extern "C" void gmupt_camera_reset_accumulation(gmupt_camera* c) { if (c) c->cam.getBuffer()->iterationCounter = -1; }
 extern "C" gmupt_camera_buffer* gmupt_camera_get_buffer(gmupt_camera* c) { return c ? c->cam.getBuffer() : nullptr; }

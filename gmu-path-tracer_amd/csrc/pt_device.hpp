@@ -49,6 +49,11 @@ struct DevStats {
     unsigned long long shRays, shInner, shLeaves, shTris;
     unsigned long long extWaveInner, extWaveTris, shWaveInner, shWaveTris; // wave-level loop iterations (SIMD efficiency = lane steps / (64 * wave iterations))
     unsigned long long extDepthHist[32]; // collect_stats: inner-node visits of the extension rays by node depth
+    // collect_stats, fused ray cast (k_cast_m) only:
+    unsigned long long laneCensus[4];     // lane-iterations without a ray / walking / holding a leaf for a full FIFO / walk finished, leaves pending
+    unsigned long long castWaves, castWaveClocks, castWaveClocksMax; // per-wave lifetime in 100 MHz ticks: sum and maximum
+    unsigned long long castWaveEndHist[32]; // wave lifetimes in 50-us buckets (all waves of the persistent grid start together)
+    unsigned long long rayInnerHist[32];    // extension rays by inner nodes visited, 16 per bucket
     uint32_t activePaths;
     uint32_t stackOverflow; // traversal needed more than the provisioned stack (results then differ from an unbounded stack)
 };

@@ -205,13 +205,6 @@ __device__ __forceinline__ void extend_body_d(const RenderParams& p, int* s_stac
             next = (next + (uint32_t)nIdle < end) ? next + (uint32_t)nIdle : end;
         }
 
-        if (STATS) { // lane census (collect_stats only): where do the 64 lanes of a wave spend the loop iterations?
-            const bool pendingNow = (qCount > 0) || (ti >= 0);
-            const uint32_t nI = __popcll(__ballot(cur == kDone && !pendingNow)), nW = __popcll(__ballot(cur >= 0));
-            const uint32_t nS = __popcll(__ballot(cur < 0 && cur != kDone)), nP = __popcll(__ballot(cur == kDone && pendingNow));
-            if ((threadIdx.x & 63) == 0) { atomicAdd(&p.stats->extDepthHist[28], (unsigned long long)nI); atomicAdd(&p.stats->extDepthHist[29], (unsigned long long)nW);
-                                           atomicAdd(&p.stats->extDepthHist[30], (unsigned long long)nS); atomicAdd(&p.stats->extDepthHist[31], (unsigned long long)nP); }
-        }
         // ---- walk: REPS inner steps per lane; a reached leaf is queued and the walk goes on with the popped node
 #pragma unroll
         for (int rep = 0; rep < REPS; rep++) {
@@ -396,6 +389,8 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_m(RenderParams p)
     const uint32_t* qSh = p.queues + (size_t)Q_SHADOW_RAY * p.P;
     uint32_t next = 0, end = 0;
     int phase = 0;
+    const unsigned long long tStart = STATS ? wall_clock64() : 0ull;
+    uint32_t rayInner = 0, census0 = 0, census1 = 0, census2 = 0, census3 = 0;
 
     bool haveRay = false;
     int kind = 0;                 // 0: extension ray, 1: shadow ray
@@ -423,6 +418,7 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_m(RenderParams p)
             }
             if (idle) {
                 if (haveRay) {
+                    if (STATS && kind == 0) { atomicAdd(&p.stats->rayInnerHist[rayInner / 16u < 31u ? rayInner / 16u : 31u], 1ull); rayInner = 0; }
                     if (kind == 0) {
                         // finish the extension ray: extensionRayCast.hlsl:218-232
                         if (distance < kFltMax) {
@@ -483,11 +479,16 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_m(RenderParams p)
             next = (next + (uint32_t)nIdle < end) ? next + (uint32_t)nIdle : end;
         }
 
+        if (STATS) { // lane census: where do the 64 lanes of a wave spend the loop iterations?
+            const bool pendingNow = (qCount > 0) || (ti >= 0);
+            census0 += __popcll(__ballot(cur == kDone && !pendingNow)); census1 += __popcll(__ballot(cur >= 0));
+            census2 += __popcll(__ballot(cur < 0 && cur != kDone)); census3 += __popcll(__ballot(cur == kDone && pendingNow));
+        }
         // ---- walk: REPS inner steps per lane; a reached leaf is queued and the walk goes on with the popped node
 #pragma unroll
         for (int rep = 0; rep < REPS; rep++) {
             if (cur >= 0) {
-                if (STATS) { if (kind == 0) tcE.inner++; else tcS.inner++; if (prefix_rank(__ballot(1)) == 0) { if (phase == 0) wInE++; else wInS++; } }
+                if (STATS) { if (kind == 0) { tcE.inner++; rayInner++; } else tcS.inner++; if (prefix_rank(__ballot(1)) == 0) { if (phase == 0) wInE++; else wInS++; } }
                 cur = inner_step_d<OVF, TOP>(ts, s_top, cur, o, invdir, stk, p.stats);
             }
             if (cur < 0 && cur != kDone && qCount < (uint32_t)kFifo) {
@@ -523,7 +524,14 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_m(RenderParams p)
         }
     }
     if (STATS) { flush_counts(p.stats, tcE, raysE, true); flush_wave_iters(p.stats, wInE, wTrE, true);
-                 flush_counts(p.stats, tcS, raysS, false); flush_wave_iters(p.stats, wInS, wTrS, false); }
+                 flush_counts(p.stats, tcS, raysS, false); flush_wave_iters(p.stats, wInS, wTrS, false);
+                 if ((threadIdx.x & 63) == 0) {
+                     const unsigned long long life = wall_clock64() - tStart;
+                     atomicAdd(&p.stats->castWaves, 1ull); atomicAdd(&p.stats->castWaveClocks, life); atomicMax(&p.stats->castWaveClocksMax, life);
+                     atomicAdd(&p.stats->castWaveEndHist[life / 5000ull < 31ull ? life / 5000ull : 31ull], 1ull);
+                     atomicAdd(&p.stats->laneCensus[0], (unsigned long long)census0); atomicAdd(&p.stats->laneCensus[1], (unsigned long long)census1);
+                     atomicAdd(&p.stats->laneCensus[2], (unsigned long long)census2); atomicAdd(&p.stats->laneCensus[3], (unsigned long long)census3);
+                 } }
 }
 
 // ------------------------------------------------------------------------------------------------ three-slot lane pipeline

@@ -5,7 +5,8 @@
 //   baseColorFactor, metallicFactor, roughnessFactor, alphaMode == "BLEND" -> GLASS (Scene.cpp:138-143).
 // assimp itself is not available (headers only in the reference, binary .lib is an LFS stub), so this is a restatement of the
 // documented effect of those flags, not of assimp's code: PARITY UNPINNED.  Image decoding / texture
-// arrays are not loaded here (texture indices stay -1).
+// arrays: the loader only fetches the encoded image of every material's baseColorTexture / metallicRoughnessTexture / normalTexture
+// (assimp's aiTextureType_DIFFUSE / _UNKNOWN / _NORMALS for glTF 2.0); decoding and layer assignment happen in TextureLoader.cpp.
 #include "MeshData.hpp"
 #include "json_min.hpp"
 #include <cmath>
@@ -210,6 +211,34 @@ MeshData MeshData::loadGltf(const std::string& path)
 		mp.textureIndices[0] = mp.textureIndices[1] = mp.textureIndices[2] = -1;
 		mp.materialType = (m["alphaMode"].string() == "BLEND") ? GMUPT_MATERIAL_GLASS : GMUPT_MATERIAL_UE4; // Scene.cpp:138-143
 		out.materials.push_back(mp);
+	}
+	// images referenced by the materials: textures[t].source -> images[i] = { uri | bufferView }
+	auto imageBytes = [&](const Json& textureInfo) -> std::vector<uint8_t> {
+		if (textureInfo.type != Json::Object) return {};
+		const Json& tex = g.doc["textures"][static_cast<size_t>(textureInfo["index"].integer(0) < 0 ? 0 : textureInfo["index"].integer(0))];
+		if (tex.type != Json::Object || tex["source"].integer(-1) < 0) return {};
+		const Json& image = g.doc["images"][static_cast<size_t>(tex["source"].integer(0))];
+		if (image.type != Json::Object) return {};
+		std::string bytes;
+		if (image.has("uri")) {
+			const std::string& uri = image["uri"].string();
+			const std::string tag = "base64,";
+			bytes = (uri.compare(0, 5, "data:") == 0 && uri.find(tag) != std::string::npos) ? decodeBase64(uri.substr(uri.find(tag) + tag.size())) : readFile(dir + uri, true);
+		} else if (image["bufferView"].integer(-1) >= 0) {
+			const Json& view = g.doc["bufferViews"][static_cast<size_t>(image["bufferView"].integer(0))];
+			const size_t buffer = static_cast<size_t>(view["buffer"].integer(0) < 0 ? 0 : view["buffer"].integer(0));
+			const size_t offset = static_cast<size_t>(view["byteOffset"].number(0.0)), length = static_cast<size_t>(view["byteLength"].number(0.0));
+			if (buffer >= g.buffers.size() || offset + length > g.buffers[buffer].size()) throw std::runtime_error("glTF: image bufferView out of range");
+			bytes = g.buffers[buffer].substr(offset, length);
+		}
+		return std::vector<uint8_t>(bytes.begin(), bytes.end());
+	};
+	for (int t = 0; t < 3; t++) out.textureFiles[t].resize(g.doc["materials"].size());
+	for (size_t i = 0; i < g.doc["materials"].size(); i++) {
+		const Json& m = g.doc["materials"][i];
+		out.textureFiles[0][i] = imageBytes(m["pbrMetallicRoughness"]["baseColorTexture"]);
+		out.textureFiles[1][i] = imageBytes(m["pbrMetallicRoughness"]["metallicRoughnessTexture"]);
+		out.textureFiles[2][i] = imageBytes(m["normalTexture"]);
 	}
 	if (out.materials.empty()) { gmupt_material mp{}; mp.color[0] = mp.color[1] = mp.color[2] = 0.6f; mp.color[3] = 1.f; mp.metallic = 0.f; mp.roughness = 1.f; mp.textureIndices[0] = mp.textureIndices[1] = mp.textureIndices[2] = -1; out.materials.push_back(mp); }
 	const Json& scenes = g.doc["scenes"];

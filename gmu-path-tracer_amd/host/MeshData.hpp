@@ -15,6 +15,9 @@ struct MeshData
 	std::vector<uint32_t> vertexMaterial; // material index of the mesh each vertex came from
 	std::vector<int32_t> indices;         // 3 per triangle
 	std::vector<gmupt_material> materials;
+	// encoded PNG file of every material per texture type (0 base colour, 1 metallic-roughness, 2 normal; empty = none):
+	// what aiMaterial::GetTexture(type, 0, &path) + the file behind `path` are to the reference (Source/Scene.cpp:218-226)
+	std::vector<std::vector<uint8_t>> textureFiles[3];
 
 	size_t numVertices() const { return vertices.size() / 3; }
 	size_t numTriangles() const { return indices.size() / 3; }

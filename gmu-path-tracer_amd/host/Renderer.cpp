@@ -1,3 +1,4 @@
+#include <cstdio>
 #include "Renderer.hpp"
 #include "png_writer.hpp"
 #include <cstdlib>
@@ -63,6 +64,8 @@ void Renderer::draw()
 	{
 		check(gmupt_renderer_bind_scene(mRenderer.get(), mScene.mBVHBuffer.get(), mScene.mIndexBuffer.get(), mScene.mVertexBuffer.get(),
 		                                mScene.mLightBuffer.get(), mScene.mTriangleProperties.get(), mScene.mMaterialPropertyBuffer.get()));
+		// CSSetShaderResources t5..t7 + sampler s0 (Renderer.cpp:173-175,192)
+		check(gmupt_renderer_bind_textures(mRenderer.get(), mScene.mDiffuse.get(), mScene.mMetallicRoughness.get(), mScene.mNormal.get()));
 		mSceneBound = true;
 	}
 	check(gmupt_iterate(mRenderer.get())); // logic, newPath, materialUE4, materialGlass, extensionRay, shadowRay (Renderer.cpp:195-211)
@@ -74,6 +77,22 @@ std::vector<float> Renderer::readFramebuffer()
 	std::vector<float> rgba(static_cast<size_t>(mResolution.first) * mResolution.second * 4);
 	check(gmupt_read_framebuffer(mRenderer.get(), rgba.data(), rgba.size() * sizeof(float)));
 	return rgba;
+}
+
+void Renderer::writePfm(const std::string& path)
+{
+	const auto rgba = readFramebuffer();
+	std::FILE* f = std::fopen(path.c_str(), "wb");
+	if (!f) throw std::runtime_error("Failed to write " + path);
+	std::fprintf(f, "PF\n%u %u\n-1.0\n", mResolution.first, mResolution.second);
+	std::vector<float> row(static_cast<size_t>(mResolution.first) * 3);
+	for (unsigned y = mResolution.second; y-- > 0;)
+	{
+		for (unsigned x = 0; x < mResolution.first; x++)
+			for (int c = 0; c < 3; c++) row[static_cast<size_t>(x) * 3 + static_cast<size_t>(c)] = rgba[(static_cast<size_t>(y) * mResolution.first + x) * 4 + static_cast<size_t>(c)];
+		std::fwrite(row.data(), sizeof(float), row.size(), f);
+	}
+	std::fclose(f);
 }
 
 void Renderer::captureScreen()

@@ -27,6 +27,7 @@ public:
 
 	// headless extras
 	std::vector<float> readFramebuffer();            // RGBA32F, a = sample count bits
+	void writePfm(const std::string& path);          // raw RGB float export ("PF", little-endian, bottom row first) for image comparisons
 	std::string lastCapturePath() const { return mLastCapture; }
 	Scene& scene() { return mScene; }
 	unsigned long long iterations() const { return mIterations; }

@@ -44,7 +44,7 @@ Scene::Scene(gmupt_device* device, const std::string& path)
 	loadScene(path);
 
 	std::thread worker(&Scene::createBVH, this); // as Source/Scene.cpp:89: BVH build + upload on a worker thread
-	createPropertyBuffer(mScene.materials);
+	loadTextures(); // decodes / resizes / uploads the three texture arrays on three threads, then uploads the material table
 
 	std::string paramsPath = path;
 	const auto dot = paramsPath.find_last_of('.');
@@ -68,6 +68,41 @@ void Scene::loadScene(const std::string& path)
 	const bool gltf = path.size() > 5 && path.compare(path.size() - 5, 5, ".gltf") == 0;
 	mScene = (path == "cornell") ? MeshData::cornell() : gltf ? MeshData::loadGltf(path) : MeshData::load(path);
 	if (mScene.materials.size() > MAX_LIGHTS) throw std::runtime_error("More than 128 materials (logic.hlsl:8)");
+}
+
+void Scene::loadTextures()
+{
+	// Source/Scene.cpp:126-166: one worker per texture type fills its textureIndices column and creates its Texture2DArray
+	std::vector<MaterialProperty>& materialProperties = mScene.materials;
+	std::string errors[3];
+	auto work = [&](int index, Buffer& resource)
+	{
+		try
+		{
+			if (mScene.textureFiles[index].empty()) return;
+			createTextures(gmupt::loadSpecificTexture(mScene.textureFiles[index], materialProperties, index), resource);
+		}
+		catch (const std::exception& e) { errors[index] = e.what(); }
+	};
+	std::thread diffWorker(work, 0, std::ref(mDiffuse));
+	std::thread mtrWorker(work, 1, std::ref(mMetallicRoughness));
+	std::thread normWorker(work, 2, std::ref(mNormal));
+	diffWorker.join();
+	mtrWorker.join();
+	normWorker.join();
+	for (const std::string& e : errors) if (!e.empty()) throw std::runtime_error(e);
+	createPropertyBuffer(materialProperties);
+}
+
+void Scene::createTextures(gmupt::TextureSet set, Buffer& resource)
+{
+	if (set.layers.empty()) return; // Scene.cpp:250-251
+	std::vector<uint8_t> packed;
+	packed.reserve(set.layers.size() * set.layers[0].size());
+	for (const auto& layer : set.layers) packed.insert(packed.end(), layer.begin(), layer.end());
+	gmupt_buffer* b = nullptr;
+	check(gmupt_texture_array_create(mDevice, packed.data(), set.dimension, static_cast<uint32_t>(set.layers.size()), &b));
+	resource.reset(b);
 }
 
 void Scene::createBVH()

@@ -8,6 +8,7 @@
 #include "Camera.hpp"
 #include "BVHWrapper.hpp"
 #include "Constants.hpp"
+#include "TextureLoader.hpp"
 
 using Light = gmupt_light;                   // Include/Scene.hpp:13-19
 using MaterialProperty = gmupt_material;     // Include/Scene.hpp:43-68
@@ -43,6 +44,8 @@ public:
 private:
 	void loadScene(const std::string& path);
 	void createBVH();
+	void loadTextures();
+	void createTextures(struct gmupt::TextureSet set, Buffer& resource);
 	void createPropertyBuffer(const std::vector<MaterialProperty>& data);
 	void createLights(const std::vector<Light>& lights);
 
@@ -57,6 +60,7 @@ private:
 	Buffer mTriangleProperties;
 	Buffer mLightBuffer;
 	Buffer mMaterialPropertyBuffer;
+	Buffer mDiffuse, mMetallicRoughness, mNormal; // Texture2DArray t5..t7 (Include/Scene.hpp:108-110); null when the scene has none
 
 	std::array<Light, MAX_LIGHTS> mLights{};
 	size_t mLightCount = 0;

@@ -1,6 +1,6 @@
 // Headless driver of the C++ host classes: the reference's Window::loop (Source/Window.cpp:60-90: update(dt); draw();)
 // without a window.  Used by tests/test_host_cpp_gpu.py.
-//   gmupt_render --scene cornell|file.gmesh --size WxH --frames N --pool P --live L [--capture] [--dump out.f32] [--build-only]
+//   gmupt_render --scene cornell|file.gmesh --size WxH --frames N --pool P --live L [--capture] [--dump out.f32] [--pfm out.pfm] [--build-only]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -13,7 +13,7 @@
 
 int main(int argc, char** argv)
 {
-	std::string scene = "cornell", dump;
+	std::string scene = "cornell", dump, pfm;
 	unsigned w = WIDTH, h = HEIGHT, frames = 16, pool = PATHCOUNT, live = REFERENCE_LIVE_PATHS;
 	bool capture = false, buildOnly = false;
 	std::string paramsOnly;
@@ -26,6 +26,7 @@ int main(int argc, char** argv)
 		else if (a == "--pool") pool = std::strtoul(next(), nullptr, 10);
 		else if (a == "--live") live = std::strtoul(next(), nullptr, 10);
 		else if (a == "--dump") dump = next();
+		else if (a == "--pfm") pfm = next();
 		else if (a == "--capture") capture = true;
 		else if (a == "--build-only") buildOnly = true;
 		else if (a == "--params") paramsOnly = next();
@@ -45,20 +46,33 @@ int main(int argc, char** argv)
 		}
 		if (buildOnly) { // host-only leg (BASELINE config 1): scene load + SBVH build + flatten, no GPU
 			const bool gltf = scene.size() > 5 && scene.compare(scene.size() - 5, 5, ".gltf") == 0;
-			const MeshData mesh = (scene == "cornell") ? MeshData::cornell() : gltf ? MeshData::loadGltf(scene) : MeshData::load(scene);
+			MeshData mesh = (scene == "cornell") ? MeshData::cornell() : gltf ? MeshData::loadGltf(scene) : MeshData::load(scene);
+			// texture ingestion without the upload: layers, common size and checksum per texture type (Scene.cpp:209-244,268-285)
+			std::string texInfo = "[";
+			for (int t = 0; t < 3; t++) {
+				gmupt::TextureSet set;
+				if (!mesh.textureFiles[t].empty()) set = gmupt::loadSpecificTexture(mesh.textureFiles[t], mesh.materials, t);
+				unsigned long long sum = 0; for (const auto& layer : set.layers) for (uint8_t v : layer) sum = sum * 31ull + v;
+				char buf[128]; std::snprintf(buf, sizeof(buf), "%s{\"layers\": %zu, \"size\": %u, \"checksum\": %llu}", t ? ", " : "", set.layers.size(), set.dimension, sum);
+				texInfo += buf;
+			}
+			texInfo += "], \"texture_indices\": [";
+			for (size_t i = 0; i < mesh.materials.size(); i++) { char buf[96]; std::snprintf(buf, sizeof(buf), "%s[%d, %d, %d]", i ? ", " : "", mesh.materials[i].textureIndices[0], mesh.materials[i].textureIndices[1], mesh.materials[i].textureIndices[2]); texInfo += buf; }
+			texInfo += "]";
 			const auto t0 = std::chrono::steady_clock::now();
 			BVHWrapper bvh(mesh);
 			const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 			float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f };
 			for (size_t i = 0; i < mesh.numVertices(); i++) for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], mesh.vertices[3 * i + k]); hi[k] = std::max(hi[k], mesh.vertices[3 * i + k]); }
 			size_t glass = 0; for (const auto& m : mesh.materials) glass += m.materialType == GMUPT_MATERIAL_GLASS;
-			std::printf("{\"triangles\": %zu, \"vertices\": %zu, \"materials\": %zu, \"glass_materials\": %zu, \"nodes\": %zu, \"references\": %zu, \"sah\": %.6f, \"build_s\": %.4f, \"bbox\": [%.6f, %.6f, %.6f, %.6f, %.6f, %.6f]}\n",
-			            mesh.numTriangles(), mesh.numVertices(), mesh.materials.size(), glass, bvh.tree().size(), bvh.indices().size(), bvh.sah(), s, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]);
+			std::printf("{\"triangles\": %zu, \"vertices\": %zu, \"materials\": %zu, \"glass_materials\": %zu, \"nodes\": %zu, \"references\": %zu, \"sah\": %.6f, \"build_s\": %.4f, \"bbox\": [%.6f, %.6f, %.6f, %.6f, %.6f, %.6f], \"textures\": %s}\n",
+			            mesh.numTriangles(), mesh.numVertices(), mesh.materials.size(), glass, bvh.tree().size(), bvh.indices().size(), bvh.sah(), s, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], texInfo.c_str());
 			return 0;
 		}
 		Renderer renderer(nullptr, { w, h }, scene, 0, pool, live);
 		for (unsigned f = 0; f < frames; f++) { renderer.update(0.f); renderer.draw(); }
 		if (capture) { renderer.requestCapture(); renderer.update(0.f); std::printf("capture %s\n", renderer.lastCapturePath().c_str()); }
+		if (!pfm.empty()) renderer.writePfm(pfm);
 		if (!dump.empty()) {
 			const auto fb = renderer.readFramebuffer();
 			FILE* f = std::fopen(dump.c_str(), "wb");

@@ -270,7 +270,23 @@ def save_gmesh(mesh, path, params_path=None):
                 f.write(", ".join(repr(float(v)) for v in row) + "\n")
 
 
-def save_gltf(mesh, path, node_transform=None, with_normals=True):
+def encode_png_rgba8(rgba):
+    """Minimal PNG writer (RGBA, 8 bit, filter 0, zlib) for the texture files of save_gltf."""
+    import struct, zlib
+    rgba = np.ascontiguousarray(rgba, np.uint8)
+    h, w = rgba.shape[:2]
+    raw = b"".join(b"\x00" + rgba[y].tobytes() for y in range(h))
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xFFFFFFFF)
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b"")
+
+
+_TEX_KEYS = ("tex_diffuse", "tex_metallic_roughness", "tex_normal")
+_GLTF_TEX_SLOTS = (("pbrMetallicRoughness", "baseColorTexture"), ("pbrMetallicRoughness", "metallicRoughnessTexture"), (None, "normalTexture"))
+
+
+def save_gltf(mesh, path, node_transform=None, with_normals=True, texture_scale=None):
     """Writes `mesh` as glTF 2.0 (.gltf + .bin next to it), one TRIANGLES primitive per material, and returns the mesh in the vertex
     order it was written (what a loader reproduces).  UVs are stored un-flipped (v -> 1 - v), as glTF files are before the reference's
     aiProcess_FlipUVs.  Optionally writes a sibling .params file (camera + lights) like save_gmesh."""
@@ -315,10 +331,36 @@ def save_gltf(mesh, path, node_transform=None, with_normals=True):
         if int(mm["materialType"]) == capi.MATERIAL_GLASS:
             d["alphaMode"] = "BLEND"
         mats.append(d)
+    # textures: one PNG file per (material, slot) that uses a layer; the loader numbers the layers in material order (Scene.cpp:221).
+    # texture_scale = {(material, slot): k} writes that image k times larger (nearest), so that the loader has to resize it.
+    images, textures, tex_files = [], [], [[], [], []]
+    stem = path.rsplit("/", 1)[-1].rsplit(".", 1)[0]
+    folder = path.rsplit("/", 1)[0] + "/" if "/" in path else ""
+    new_materials = np.array(mesh["materials"], copy=True)
+    for i, mm in enumerate(mesh["materials"]):
+        for t, key in enumerate(_TEX_KEYS):
+            layer = int(mm["textureIndices"][t])
+            if layer < 0 or mesh.get(key) is None:
+                new_materials[i]["textureIndices"][t] = -1
+                continue
+            img = mesh[key][layer]
+            k = (texture_scale or {}).get((i, t), 1)
+            if k != 1:
+                img = np.kron(img, np.ones((k, k, 1), np.uint8))
+            data = encode_png_rgba8(img)
+            name = "%s_m%d_t%d.png" % (stem, i, t)
+            with open(folder + name, "wb") as f:
+                f.write(data)
+            images.append({"uri": name}); textures.append({"source": len(images) - 1})
+            group, slot = _GLTF_TEX_SLOTS[t]
+            (mats[i][group] if group else mats[i])[slot] = {"index": len(textures) - 1}
+            new_materials[i]["textureIndices"][t] = len(tex_files[t])
+            tex_files[t].append(data)
     node = {"mesh": 0}
     if node_transform:
         node.update(node_transform)
     doc = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}], "nodes": [node], "meshes": [{"primitives": prims}], "materials": mats,
+           **({"images": images, "textures": textures} if images else {}),
            "accessors": accessors, "bufferViews": views, "buffers": [{"uri": path.rsplit("/", 1)[-1].rsplit(".", 1)[0] + ".bin", "byteLength": len(blob)}]}
     with open(path, "w") as f:
         _json.dump(doc, f)
@@ -330,6 +372,10 @@ def save_gltf(mesh, path, node_transform=None, with_normals=True):
             L = mesh["lights"][i]
             f.write(", ".join(repr(float(v)) for v in list(L["position"]) + [L["falloff"]] + list(L["emission"]) + [L["radius"]]) + "\n")
     out = dict(mesh)
+    out["materials"] = new_materials
+    out["texture_files"] = tex_files  # encoded PNGs per slot in layer order: capi.texture_array_from_png() turns them into the arrays
+    for key in _TEX_KEYS:
+        out.pop(key, None)
     out.update({"verts": np.concatenate(verts), "normals": np.concatenate(normals), "uv": np.concatenate(uvs), "vertex_material": np.concatenate(vmat),
                 "indices": np.concatenate(tris)})
     return out

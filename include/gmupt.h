@@ -101,6 +101,17 @@ size_t gmupt_buffer_size(const gmupt_buffer* buf);
  * (the caller has already resized every layer to the common size, as the reference does with avir) */
 int gmupt_texture_array_create(gmupt_device* dev, const uint8_t* rgba8, uint32_t size, uint32_t layers, gmupt_buffer** out);
 
+/* Host-side image helpers for the texture path (no device work).
+ * gmupt_image_decode_png replaces lodepng::decode(out, w, h, file) (Source/Scene.cpp:226): PNG file bytes -> tightly packed RGBA8;
+ * *rgba is allocated by the library, release it with gmupt_image_free.
+ * gmupt_image_resize_square replaces avir::CImageResizer::resizeImage on square RGBA8 layers (Scene.cpp:269-279); own Lanczos-3 filter,
+ * parity with avir unpinned; dst holds new_size * new_size * 4 bytes.
+ * gmupt_texture_common_size is the reference's size rule (Scene.cpp:232-241): median of the DISTINCT layer byte sizes -> width. */
+int gmupt_image_decode_png(const void* png, size_t bytes, uint32_t* width, uint32_t* height, uint8_t** rgba);
+void gmupt_image_free(uint8_t* rgba);
+int gmupt_image_resize_square(const uint8_t* rgba, uint32_t old_size, uint32_t new_size, uint8_t* dst);
+uint32_t gmupt_texture_common_size(const size_t* layer_bytes, uint32_t layers);
+
 /* ---- renderer ---- */
 typedef struct {
     uint32_t width, height;      /* accumulation target (== tile size when tile_enabled); createRenderTexture, Renderer.cpp:110-142 */
@@ -159,6 +170,11 @@ typedef struct {
     /* collect_stats only: wave-level loop iterations of the ray casts; SIMD efficiency = lane steps / (64 * wave iterations) */
     uint64_t ext_wave_inner, ext_wave_tris, sh_wave_inner, sh_wave_tris;
     uint64_t ext_depth_hist[32]; /* inner-node visits of the extension rays by node depth */
+    /* collect_stats with the fused ray cast (GMUPT_STAT_FUSED_CAST) only */
+    uint64_t lane_census[4];          /* lane-iterations: no ray / walking / holding a leaf for a full FIFO / walk done, leaves pending */
+    uint64_t cast_waves, cast_wave_ticks, cast_wave_ticks_max; /* wave lifetimes in 100 MHz ticks: count, sum, maximum */
+    uint64_t cast_wave_end_hist[32];  /* wave lifetimes in 50-us buckets */
+    uint64_t ray_inner_hist[32];      /* extension rays by inner nodes visited, 16 per bucket */
 } gmupt_stats;
 int gmupt_get_stats(gmupt_renderer* r, gmupt_stats* out); /* synchronises */
 int gmupt_reset_stats(gmupt_renderer* r);
@@ -212,6 +228,10 @@ void gmupt_camera_update_resolution(gmupt_camera* c, uint32_t width, uint32_t he
 void gmupt_camera_set_pose(gmupt_camera* c, float x, float y, float z, float pitch, float yaw); /* Scene.cpp:95-97 */
 void gmupt_camera_update(gmupt_camera* c, float dt); /* Camera::update without input devices */
 void gmupt_camera_reset_accumulation(gmupt_camera* c); /* iterationCounter = -1 (Renderer.cpp:152) */
+/* input for the next gmupt_camera_update calls: mouse delta in degrees (yaw += dx, pitch -= dy, consumed by one update; Camera.cpp:28-33) and the
+ * W/S/A/D key states (bit 0..3, held until changed; 5 units/s, :47-57).  Any input restarts the accumulation by the reference's
+ * hysteresis rule (:72-83): iterationCounter -> 0 when it is > 4, and once more when the motion has stopped. */
+void gmupt_camera_set_input(gmupt_camera* c, float mouse_dx, float mouse_dy, uint32_t keys_wsad);
 gmupt_camera_buffer* gmupt_camera_get_buffer(gmupt_camera* c);
 
 const char* gmupt_version(void);

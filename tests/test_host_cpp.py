@@ -53,6 +53,31 @@ def test_gltf_loader_matches_written_mesh(exe, pkg, tmp_path):
     assert out2["triangles"] == 34
 
 
+def _textured_gltf(pkg, tmp_path):
+    path = str(tmp_path / "tex.gltf")
+    # material 0's base colour image is written 2x larger: three distinct-size rule -> the loader resizes layers to the median size
+    written = pkg.scenes.save_gltf(pkg.scenes.textured_mesh(), path, texture_scale={(0, 0): 2, (0, 2): 2, (2, 2): 2})
+    arrays = [pkg.capi.texture_array_from_png(f) if f else None for f in written["texture_files"]]
+    return path, written, arrays
+
+
+def test_gltf_textures_are_decoded_indexed_and_resized(exe, pkg, tmp_path):
+    # f3: images of baseColorTexture / metallicRoughnessTexture / normalTexture -> layers in material order, common size by the
+    # median rule (Scene.cpp:209-244), resized where they differ (:268-285)
+    path, written, arrays = _textured_gltf(pkg, tmp_path)
+    out = json.loads(subprocess.run([exe, "--build-only", "--scene", path], check=True, capture_output=True, text=True).stdout)
+    assert out["texture_indices"] == [[int(v) for v in m["textureIndices"]] for m in written["materials"]]
+    assert out["texture_indices"][0] == [0, 0, 0] and out["texture_indices"][1] == [1, -1, -1] and out["texture_indices"][2] == [-1, 1, 1]
+    for t, arr in enumerate(arrays):
+        info = out["textures"][t]
+        assert info["layers"] == arr.shape[0] and info["size"] == arr.shape[1]
+        chk = 0
+        for v in arr.reshape(-1).tolist():
+            chk = (chk * 31 + v) & 0xFFFFFFFFFFFFFFFF
+        assert info["checksum"] == chk
+    assert [a.shape[1] for a in arrays] == [32, 16, 32]     # {16, 32} -> 32; all 16 -> 16; both normal maps doubled -> 32
+
+
 def test_reference_params_files_parse(exe, tmp_path):
     # the values of the reference's own .params data files (tests/golden/reference_params.json), written back as CSV and parsed by
     # SceneParams::load (Source/Scene.cpp:34-55)
@@ -90,7 +115,7 @@ def test_cpp_renderer_equals_capi_render(exe, pkg, device, tmp_path):
     W, H, P, frames = 48, 27, 4096, 20
     dump = str(tmp_path / "fb.f32")
     subprocess.run([exe, "--scene", path, "--size", "%dx%d" % (W, H), "--frames", str(frames), "--pool", str(P), "--live", str(P),
-                    "--dump", dump, "--capture"], check=True, cwd=str(tmp_path))
+                    "--dump", dump, "--capture", "--pfm", str(tmp_path / "fb.pfm")], check=True, cwd=str(tmp_path))
     fb_cpp = np.fromfile(dump, dtype=np.float32).reshape(H, W, 4)
     scene = pkg.scenes.build_scene(mesh)
     sb = pkg.capi.SceneBuffers(device, scene)
@@ -100,9 +125,44 @@ def test_cpp_renderer_equals_capi_render(exe, pkg, device, tmp_path):
     for _ in range(frames):
         cam.update(0.0); r.set_camera(cam.buffer); r.iterate()
     assert np.array_equal(fb_cpp.view(np.uint32), r.framebuffer().view(np.uint32))
+    raw = (tmp_path / "fb.pfm").read_bytes()                                  # f2: raw float export next to the 8-bit capture
+    head = b"PF\n%d %d\n-1.0\n" % (W, H)
+    assert raw.startswith(head) and np.array_equal(np.frombuffer(raw[len(head):], "<f4").reshape(H, W, 3)[::-1], fb_cpp[..., :3])
     png = tmp_path / "Captures" / "potato0.png"                               # Renderer.cpp:404 naming
     assert png.exists() and png.read_bytes()[:8] == b"\x89PNG\r\n\x1a\n"
     from PIL import Image
     img = np.asarray(Image.open(str(png)))
     assert img.shape == (H, W, 4) and np.array_equal(img[..., :3], (fb_cpp[..., :3] * 255).astype(np.uint8)) and np.all(img[..., 3] == 255)
     r.close(); sb.close()
+
+
+@pytest.mark.gpu
+def test_cpp_renderer_with_gltf_textures_equals_capi_render(exe, pkg, device, tmp_path):
+    # the three Texture2DArrays built by Scene::loadTextures from the glTF's PNG files drive the same pixels as the arrays
+    # built from the same files through the C-ABI helpers
+    path, written, arrays = _textured_gltf(pkg, tmp_path)
+    W, H, P, frames = 40, 30, 2048, 24
+    dump = str(tmp_path / "fb_tex.f32")
+    subprocess.run([exe, "--scene", path, "--size", "%dx%d" % (W, H), "--frames", str(frames), "--pool", str(P), "--live", str(P), "--dump", dump], check=True, cwd=str(tmp_path))
+    fb_cpp = np.fromfile(dump, dtype=np.float32).reshape(H, W, 4)
+    scene = pkg.scenes.build_scene(written)
+    for key, arr in zip(("tex_diffuse", "tex_metallic_roughness", "tex_normal"), arrays):
+        scene[key] = arr
+    sb = pkg.capi.SceneBuffers(device, scene)
+    r = pkg.capi.Renderer(device, W, H, pool_paths=P); r.bind_scene(sb)
+    cam = pkg.capi.Camera(W, H); cam.set_pose(*scene["camera"])
+    for _ in range(frames):
+        cam.update(0.0); r.set_camera(cam.buffer); r.iterate()
+    fb = r.framebuffer()
+    assert np.array_equal(fb_cpp.view(np.uint32), fb.view(np.uint32))
+    # and the textures matter: the same scene without them renders differently
+    for key in ("tex_diffuse", "tex_metallic_roughness", "tex_normal"):
+        scene[key] = None
+    scene["materials"] = scene["materials"].copy(); scene["materials"]["textureIndices"] = -1
+    sb2 = pkg.capi.SceneBuffers(device, scene)
+    r2 = pkg.capi.Renderer(device, W, H, pool_paths=P); r2.bind_scene(sb2)
+    cam2 = pkg.capi.Camera(W, H); cam2.set_pose(*scene["camera"])
+    for _ in range(frames):
+        cam2.update(0.0); r2.set_camera(cam2.buffer); r2.iterate()
+    assert not np.array_equal(fb.view(np.uint32), r2.framebuffer().view(np.uint32))
+    r.close(); sb.close(); r2.close(); sb2.close()

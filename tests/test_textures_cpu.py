@@ -1,0 +1,122 @@
+"""f3, host side: PNG decoding, the common-size rule and the square resize that feed the texture arrays
+(reference Source/Scene.cpp:209-290: lodepng::decode, median of the distinct sizes, avir resize).  No GPU."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import png_util
+
+
+@pytest.mark.parametrize("color_type,depth", [(0, 1), (0, 2), (0, 4), (0, 8), (0, 16), (2, 8), (2, 16), (3, 1), (3, 2), (3, 4), (3, 8), (4, 8), (4, 16), (6, 8), (6, 16)])
+@pytest.mark.parametrize("interlace", [False, True])
+def test_png_decoder_all_formats(pkg, color_type, depth, interlace):
+    rng = np.random.default_rng(color_type * 100 + depth + (7 if interlace else 0))
+    h, w = 13, 21                                  # odd sizes: partial bytes at row ends, empty / ragged Adam7 passes
+    ch = png_util.CHANNELS[color_type]
+    palette = rng.integers(0, 256, ((1 << depth), 3)) if color_type == 3 else None
+    samples = rng.integers(0, 1 << depth, (h, w, ch))
+    trns = None
+    if color_type == 3:
+        trns = bytes(rng.integers(0, 256, max(1, (1 << depth) // 2)).astype(np.uint8))
+    elif color_type == 0:
+        trns = struct.pack(">H", int(samples[3, 4, 0]))
+    elif color_type == 2:
+        trns = struct.pack(">HHH", *[int(v) for v in samples[5, 6]])
+    data = png_util.encode(samples, color_type, depth, filters=(0, 1, 2, 3, 4), interlace=interlace, palette=palette, trns=trns, idat_split=37)
+    got = pkg.capi.decode_png(data)
+    assert got.shape == (h, w, 4)
+    assert np.array_equal(got, png_util.expected_rgba(samples, color_type, depth, palette, trns))
+
+
+def test_png_decoder_agrees_with_pillow_and_handles_deflate_block_types(pkg, tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    img = np.zeros((64, 64, 4), np.uint8)
+    yy, xx = np.mgrid[0:64, 0:64]
+    img[..., 0] = 4 * xx; img[..., 1] = 4 * yy; img[..., 2] = ((xx // 8 + yy // 8) % 2) * 255; img[..., 3] = 255
+    img[20:40, 20:40] = rng.integers(0, 256, (20, 20, 4))
+    for level in (0, 1, 9):                        # stored blocks, fixed/dynamic Huffman with long matches
+        data = png_util.encode(img, 6, 8, filters=(4,), level=level)
+        assert np.array_equal(pkg.capi.decode_png(data), img)
+    path = tmp_path / "pil.png"
+    Image.fromarray(img).save(str(path), optimize=True)
+    assert np.array_equal(pkg.capi.decode_png(path.read_bytes()), img)
+    Image.fromarray(img[..., :3]).convert("P", palette=Image.ADAPTIVE, colors=16).save(str(path))
+    assert np.array_equal(pkg.capi.decode_png(path.read_bytes()), np.asarray(Image.open(str(path)).convert("RGBA")))
+    # a 1x1 image and a large flat one (long runs: overlapping copies)
+    assert np.array_equal(pkg.capi.decode_png(png_util.encode(img[:1, :1], 6, 8)), img[:1, :1])
+    flat = np.full((300, 300, 4), 77, np.uint8)
+    assert np.array_equal(pkg.capi.decode_png(png_util.encode(flat, 6, 8, level=9)), flat)
+
+
+def test_png_decoder_rejects_damaged_files(pkg):
+    img = np.random.default_rng(1).integers(0, 256, (8, 8, 4)).astype(np.uint8)
+    good = png_util.encode(img, 6, 8)
+    E = pkg.capi.GmuptError
+    with pytest.raises(E, match="signature"):
+        pkg.capi.decode_png(b"JUNK" + good[4:])
+    bad = bytearray(good); bad[40] ^= 0x55
+    with pytest.raises(E, match="CRC"):
+        pkg.capi.decode_png(bytes(bad))
+    with pytest.raises(E):
+        pkg.capi.decode_png(good[:len(good) // 2])
+    # valid container, corrupt compressed stream (Adler-32)
+    raw = b"".join(b"\x00" + img[y].tobytes() for y in range(8))
+    z = bytearray(zlib.compress(raw)); z[-1] ^= 1
+    broken = good[:8] + png_util.chunk(b"IHDR", struct.pack(">IIBBBBB", 8, 8, 8, 6, 0, 0, 0)) + png_util.chunk(b"IDAT", bytes(z)) + png_util.chunk(b"IEND", b"")
+    with pytest.raises(E, match="Adler"):
+        pkg.capi.decode_png(broken)
+    with pytest.raises(E, match="bit depth"):
+        pkg.capi.decode_png(good[:8] + png_util.chunk(b"IHDR", struct.pack(">IIBBBBB", 8, 8, 4, 6, 0, 0, 0)) + good[33:])
+    with pytest.raises(E, match="critical"):
+        pkg.capi.decode_png(good[:33] + png_util.chunk(b"XXXX", b"1") + good[33:])
+
+
+def test_common_size_is_the_median_of_the_distinct_sizes(pkg):
+    f = pkg.capi.texture_common_size
+    b = lambda n: n * n * 4
+    assert f([b(256)]) == 256
+    assert f([b(256), b(512)]) == 512                         # two distinct sizes: element [1]
+    assert f([b(256), b(256), b(256), b(1024)]) == 1024       # duplicates do not count (std::set, Scene.cpp:212,228)
+    assert f([b(1024), b(64), b(512)]) == 512
+    assert f([b(2048), b(64), b(512), b(128)]) == 512
+    assert f([]) == 0
+
+
+def test_resize_square_properties(pkg):
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (32, 32, 4)).astype(np.uint8)
+    assert np.array_equal(pkg.capi.resize_square(img, 32), img)               # same size: passed through bit for bit
+    flat = np.full((48, 48, 4), (10, 128, 255, 77), np.uint8)
+    for n in (16, 31, 48, 100):
+        assert np.array_equal(pkg.capi.resize_square(flat, n), np.full((n, n, 4), (10, 128, 255, 77), np.uint8))   # weights sum to 1
+    yy, xx = np.mgrid[0:64, 0:64]
+    ramp = np.stack([3 * xx + 10, 3 * yy + 20, xx + yy + 30, np.full_like(xx, 255)], axis=-1).astype(np.uint8)
+    half = pkg.capi.resize_square(ramp, 32)
+    box = ramp.reshape(32, 2, 32, 2, 4).mean(axis=(1, 3))
+    assert np.abs(half[2:-2, 2:-2].astype(np.float64) - box[2:-2, 2:-2]).max() <= 1.0     # a linear ramp is reproduced away from the clamped edge
+    up = pkg.capi.resize_square(ramp, 128)
+    ref = np.broadcast_to(3 * ((np.arange(128) + 0.5) / 2 - 0.5) + 10, (128, 128))      # red = 3 x + 10 at the source position of each texel
+    assert np.abs(up[8:-8, 8:-8, 0].astype(np.float64) - ref[8:-8, 8:-8]).max() <= 1.0
+    # a checkerboard at the Nyquist rate shrinks to its mean: the filter is stretched when reducing (no aliasing)
+    chk = np.where(((xx + yy) % 2)[..., None] == 0, 255, 0).astype(np.uint8).repeat(4, axis=-1)
+    small = pkg.capi.resize_square(chk, 16)
+    assert np.abs(small[2:-2, 2:-2].astype(np.float64) - 127.5).max() <= 8.0
+    with pytest.raises(pkg.capi.GmuptError):
+        pkg.capi._check(pkg.capi.lib().gmupt_image_resize_square(None, 4, 4, None))
+
+
+def test_texture_array_from_png_resizes_to_the_common_size(pkg):
+    rng = np.random.default_rng(2)
+    a = rng.integers(0, 256, (16, 16, 4)).astype(np.uint8)
+    b = rng.integers(0, 256, (32, 32, 4)).astype(np.uint8)
+    c = rng.integers(0, 256, (32, 32, 4)).astype(np.uint8)
+    files = [pkg.scenes.encode_png_rgba8(x) for x in (a, b, c)]
+    arr = pkg.capi.texture_array_from_png(files)
+    assert arr.shape == (3, 32, 32, 4)
+    assert np.array_equal(arr[1], b) and np.array_equal(arr[2], c) and np.array_equal(arr[0], pkg.capi.resize_square(a, 32))
+    with pytest.raises(pkg.capi.GmuptError, match="square"):
+        pkg.capi.texture_array_from_png([pkg.scenes.encode_png_rgba8(np.zeros((4, 8, 4), np.uint8))])
