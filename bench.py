@@ -160,7 +160,7 @@ def main():
         fused = bool(s2.flags & capi.STAT_FUSED_CAST)   # one launch casts the extension AND the shadow rays: its bytes are the sum
         if fused:
             nbytes += shadow_bytes(s2.sh_rays, s2.sh_inner, s2.sh_tris)
-        kname = "k_cast_m" if fused else "k_extend_d"
+        kname = {"cast0": "k_cast_f", "cast3": "k_cast_f", "cast2": "k_cast_m", "cast1": "k_cast_d"}.get(os.environ.get("GMUPT_TRAVERSAL", "cast0"), "k_cast_f") if fused else "k_extend_d"
         per_launch = nbytes / max(args.steps, 1)
         achieved = per_launch / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
         traffic = None

@@ -252,7 +252,7 @@ extern "C" void gmupt_renderer_destroy(gmupt_renderer* r)
 // GMUPT_TRAVERSAL selects a rung of the traversal ladder; all rungs give identical results, the default is the fastest
 static int parse_traversal_mode(const char* tv)
 {
-    constexpr int kDefault = 60;                                            // cast0: both ray casts in one mixed-lane persistent launch
+    constexpr int kDefault = 60;                                            // cast0: both ray casts in one mixed-lane persistent launch, fetches fused
     if (!tv || !*tv) return kDefault;
     if (std::strcmp(tv, "whilewhile") == 0) return 0;
     if (std::strcmp(tv, "ref") == 0) return 1;
@@ -262,7 +262,7 @@ static int parse_traversal_mode(const char* tv)
     if (std::strcmp(tv, "top") == 0) return 30;
     if (std::strncmp(tv, "def", 3) == 0) return 40 + std::atoi(tv + 3);     // separate deferred-leaf launches
     if (std::strncmp(tv, "pipe", 4) == 0) return 50 + std::atoi(tv + 4);    // three-slot lane pipeline
-    if (std::strncmp(tv, "cast", 4) == 0) return 60 + std::atoi(tv + 4);    // cast0 mixed lanes, cast1 extension then shadow per wave
+    if (std::strncmp(tv, "cast", 4) == 0) return 60 + std::atoi(tv + 4);    // cast0 mixed lanes + fused fetches, cast1 extension then shadow per wave, cast2 mixed lanes
     return kDefault;
 }
 
@@ -297,7 +297,7 @@ extern "C" int gmupt_renderer_create(gmupt_device* dev, const gmupt_renderer_des
     { const char* wpc = std::getenv("GMUPT_WAVES_PER_CU"); const uint32_t w = wpc ? (uint32_t)std::atoi(wpc) : 16u; const uint32_t db = deferred_block_threads(); p.travGridBlocks = (uint32_t)dev->prop.multiProcessorCount * ((w * 64 + db - 1) / db); if (p.travGridBlocks * db > p.ovfStride) p.travGridBlocks = p.ovfStride / db; if (p.travGridBlocks == 0) p.travGridBlocks = 1; }
     { const char* ep = std::getenv("GMUPT_EXTEND_PRUNE"); p.extendPrune = ep ? (uint32_t)std::atoi(ep) : 0u; }
     { const char* sp = std::getenv("GMUPT_SHADOW_PRUNE"); p.shadowPrune = sp ? (uint32_t)std::atoi(sp) : 0u; }
-    { const char* e1 = std::getenv("GMUPT_REFILL"); p.tuneRefill = e1 ? (uint32_t)std::atoi(e1) : 20u; const char* e2 = std::getenv("GMUPT_TRI_THRESH"); p.tuneTriThresh = e2 ? (uint32_t)std::atoi(e2) : 32u; }
+    { const char* e1 = std::getenv("GMUPT_REFILL"); p.tuneRefill = e1 ? (uint32_t)std::atoi(e1) : 20u; const char* e2 = std::getenv("GMUPT_TRI_THRESH"); p.tuneTriThresh = e2 ? (uint32_t)std::atoi(e2) : ((r->travMode == 60 || r->travMode == 63) ? 24u : 32u); } // fused fetches make a burst cheaper
 
     int rc = GMUPT_OK;
     // Renderer::createBuffers creates the UAV buffers without initial data: D3D11 zero-initialises them

@@ -89,7 +89,10 @@ static_assert(sizeof(Node64) == 64 && sizeof(Tri48) == 48, "packed traversal rec
 // quarters of one record with a single LDS-DMA instruction.  Triangle record: r0..r2 as Tri48, r3 = (v0, v1, v2, materialID).
 struct alignas(64) Rec64 { float q[16]; };
 
-constexpr int kTopTreeNodes = 256; // inner nodes (breadth-first from the root) that the ray-cast kernels keep in LDS: 16 KB
+#ifndef GMUPT_TOP_NODES
+#define GMUPT_TOP_NODES 256
+#endif
+constexpr int kTopTreeNodes = GMUPT_TOP_NODES; // inner nodes (breadth-first from the root) that the ray-cast kernels keep in LDS: 16 KB
 
 struct TravScene {
     const Rec64* recs;

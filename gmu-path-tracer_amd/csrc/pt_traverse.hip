@@ -57,17 +57,78 @@ struct DefStack {
     }
 };
 
-template <bool OVF, bool TOP>
-__device__ __forceinline__ int inner_step_d(const TravScene& ts, const float4* s_top, int cur, f3 o, f3 invdir, DefStack<OVF>& stk, DevStats* dst)
+// Node fetch with EXPLICIT address spaces.  Written with generic pointers, the compiler merges the two branches into one FLAT load
+// from a selected address (shared aperture or global): correct, but a FLAT access to LDS goes through the texture addresser like a
+// global one, and that unit is what bounds this kernel.  Typed pointers keep an LDS read a ds_read_b128 and a global read a
+// global_load_dwordx4, each under its own exec mask.
+typedef float vec4f __attribute__((ext_vector_type(4)));
+typedef int vec2i __attribute__((ext_vector_type(2)));
+#define GMUPT_AS_LDS __attribute__((address_space(3)))
+#define GMUPT_AS_GLOBAL __attribute__((address_space(1)))
+
+template <bool TOP>
+__device__ __forceinline__ void load_node(const TravScene& ts, const float4* s_top, int cur, vec4f& a, vec4f& b, vec4f& c, vec2i& d)
 {
-    float4 a, b, c; int4 d;
-    if (TOP && (uint32_t)cur < ts.topCount) { // the first levels of the tree live in LDS (48 % of all inner-node visits on the bench scene)
-        const float4* n = s_top + cur * 4;
-        a = n[0]; b = n[1]; c = n[2]; d = *reinterpret_cast<const int4*>(n + 3);
-    } else {
-        const float4* n = reinterpret_cast<const float4*>(ts.nodes + cur);
-        a = n[0]; b = n[1]; c = n[2]; d = *reinterpret_cast<const int4*>(n + 3);
+    // LDS lanes first: the global lanes then only wait for the (short) LDS reads before their loads may target the same registers,
+    // and nothing waits for the global loads before they are used
+    const bool inTop = TOP && (uint32_t)cur < ts.topCount;
+    if (inTop) {
+        const GMUPT_AS_LDS vec4f* n = (const GMUPT_AS_LDS vec4f*)(s_top) + cur * 4;
+        a = n[0]; b = n[1]; c = n[2]; d = *(const GMUPT_AS_LDS vec2i*)(n + 3);
     }
+    asm volatile("" ::: "memory"); // keeps the two regions apart and in this order (the optimiser would fold them into if / else, global first)
+    if (!inTop) {
+        const GMUPT_AS_GLOBAL vec4f* n = (const GMUPT_AS_GLOBAL vec4f*)(ts.nodes) + (size_t)cur * 4;
+        a = n[0]; b = n[1]; c = n[2];
+        const unsigned long long links = *(const GMUPT_AS_GLOBAL unsigned long long*)(n + 3);  // exactly 8 bytes: no spare destination registers
+        d.x = (int)(uint32_t)links; d.y = (int)(uint32_t)(links >> 32);
+    }
+}
+
+// The same fetches as raw buffer loads: exactly 3 x 16 + 8 bytes per node and 2 x 16 + 8 per triangle record, one request each, no
+// re-grouping by the optimiser (which turns the triangle record into four overlapping loads and the 8-byte link pair into 16 bytes,
+// i.e. spare destination registers that later instructions have to wait for), and hardware bounds checking for free.
+typedef uint32_t vec4u __attribute__((ext_vector_type(4)));
+typedef uint32_t vec2u __attribute__((ext_vector_type(2)));
+constexpr int kBufferRsrcFlags = 0x00020000; // raw buffer, 32-bit data format (gfx9 family)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, kBufferRsrcFlags);
+}
+
+template <bool TOP>
+__device__ __forceinline__ void load_node_buf(__amdgpu_buffer_rsrc_t nodes, const float4* s_top, uint32_t topCount, int cur, vec4f& a, vec4f& b, vec4f& c, vec2i& d)
+{
+    const bool inTop = TOP && (uint32_t)cur < topCount;
+    if (inTop) {
+        const GMUPT_AS_LDS vec4f* n = (const GMUPT_AS_LDS vec4f*)(s_top) + cur * 4;
+        a = n[0]; b = n[1]; c = n[2]; d = *(const GMUPT_AS_LDS vec2i*)(n + 3);
+    }
+    asm volatile("" ::: "memory"); // LDS lanes first, see load_node
+    if (!inTop) {
+        const int off = cur * 64;
+        a = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off, 0, 0));
+        b = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 16, 0, 0));
+        c = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 32, 0, 0));
+        d = __builtin_bit_cast(vec2i, __builtin_amdgcn_raw_buffer_load_b64(nodes, off + 48, 0, 0));
+    }
+}
+
+typedef float vec2f __attribute__((ext_vector_type(2)));
+// (whole-vector bit casts only: __builtin_bit_cast of a vector ELEMENT lvalue reads element 0 with this compiler)
+__device__ __forceinline__ void tri_fetch_buf(__amdgpu_buffer_rsrc_t tris, int i, vec4f& r0, vec4f& r1, vec2f& r2)
+{
+    const int off = i * 48;
+    r0 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(tris, off, 0, 0));
+    r1 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(tris, off + 16, 0, 0));
+    r2 = __builtin_bit_cast(vec2f, __builtin_amdgcn_raw_buffer_load_b64(tris, off + 32, 0, 0));
+}
+
+// both slab tests of a fetched node, then the reference's choice (extensionRayCast.hlsl:132-159)
+template <bool OVF>
+__device__ __forceinline__ int inner_compute(const vec4f a, const vec4f b, const vec4f c, const vec2i d, f3 o, f3 invdir, DefStack<OVF>& stk, DevStats* dst)
+{
     const float leftHit = ray_box(a.x, a.y, a.z, a.w, b.x, b.y, o, invdir);
     const float rightHit = ray_box(b.z, b.w, c.x, c.y, c.z, c.w, o, invdir);
     const bool l = leftHit > 0.0f, r = rightHit > 0.0f;
@@ -75,6 +136,14 @@ __device__ __forceinline__ int inner_step_d(const TravScene& ts, const float4* s
     if (l && r) { stk.push(swap ? d.x : d.y, dst); return swap ? d.y : d.x; }
     if (l | r) return l ? d.x : d.y;
     return stk.pop();
+}
+
+template <bool OVF, bool TOP>
+__device__ __forceinline__ int inner_step_d(const TravScene& ts, const float4* s_top, int cur, f3 o, f3 invdir, DefStack<OVF>& stk, DevStats* dst)
+{
+    vec4f a, b, c; vec2i d;
+    load_node<TOP>(ts, s_top, cur, a, b, c, d); // the first levels of the tree live in LDS (48 % of all inner-node visits on the bench scene)
+    return inner_compute<OVF>(a, b, c, d, o, invdir, stk, dst);
 }
 
 // OPT-IN inner step with distance pruning (GMUPT_EXTEND_PRUNE=1 / GMUPT_SHADOW_PRUNE=1; both default to 0).
@@ -90,14 +159,8 @@ __device__ __forceinline__ int inner_step_d(const TravScene& ts, const float4* s
 template <bool OVF, bool TOP>
 __device__ __forceinline__ int inner_step_pruned(const TravScene& ts, const float4* s_top, int cur, f3 o, f3 invdir, float limitT, DefStack<OVF>& stk, DevStats* dst)
 {
-    float4 a, b, c; int4 d;
-    if (TOP && (uint32_t)cur < ts.topCount) {
-        const float4* n = s_top + cur * 4;
-        a = n[0]; b = n[1]; c = n[2]; d = *reinterpret_cast<const int4*>(n + 3);
-    } else {
-        const float4* n = reinterpret_cast<const float4*>(ts.nodes + cur);
-        a = n[0]; b = n[1]; c = n[2]; d = *reinterpret_cast<const int4*>(n + 3);
-    }
+    vec4f a, b, c; vec2i d;
+    load_node<TOP>(ts, s_top, cur, a, b, c, d);
     float le, re;
     const float leftHit = ray_box_entry(a.x, a.y, a.z, a.w, b.x, b.y, o, invdir, le);
     const float rightHit = ray_box_entry(b.z, b.w, c.x, c.y, c.z, c.w, o, invdir, re);
@@ -534,6 +597,177 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_m(RenderParams p)
                  } }
 }
 
+// k_cast_m with the two fetches of a loop step issued together: when the wave is in a triangle burst, every step first issues the node
+// fetch of the walking lanes AND the triangle fetch of the lanes with a pending leaf, then does the slab tests and the triangle test.
+// A burst therefore costs no memory round trips of its own (4 per loop iteration instead of 8); what is tested, and in which order per
+// ray, is unchanged: leaves leave the per-lane FIFO in visit order.
+template <bool STATS, bool OVF, bool TOP, int REPS, int BURST>
+__global__ __launch_bounds__(kDefBlock) void k_cast_f(RenderParams p)
+{
+    GMUPT_DEF_LDS(TOP)
+    shadow_counter_epilogue(p);
+    const uint32_t gtid = blockIdx.x * kDefBlock + threadIdx.x;
+    DefStack<OVF> stk; stk.lds = s_stack + threadIdx.x; stk.ovf = p.ovfStack + gtid; stk.ovfStride = p.ovfStride; stk.ptr = 1;
+    s_stack[threadIdx.x] = kDone;
+    int* fifo = s_fifo + threadIdx.x;
+    TravCount tcE = { 0, 0, 0 }, tcS = { 0, 0, 0 }; uint32_t raysE = 0, raysS = 0, wInE = 0, wTrE = 0, wInS = 0, wTrS = 0;
+    const TravScene& ts = p.trav;
+    const uint32_t countExt = p.qc[QC_EXT_COUNT], countSh = p.qc[QC_SHADOWRAY];  // extensionRayCast.hlsl:205, shadowRayCast.hlsl:151
+    const uint32_t* qExt = p.queues + (size_t)Q_EXT_RAY * p.P;
+    const uint32_t* qSh = p.queues + (size_t)Q_SHADOW_RAY * p.P;
+    const __amdgpu_buffer_rsrc_t rNodes = make_rsrc(ts.nodes, ts.triBase * 64u);              // ts.triBase = number of packed nodes
+    const __amdgpu_buffer_rsrc_t rTris = make_rsrc(ts.tris, (p.scene.numTris + 1u) * 48u);    // + the sentinel record
+    uint32_t next = 0, end = 0;
+    int phase = 0;
+    const unsigned long long tStart = STATS ? wall_clock64() : 0ull;
+    uint32_t rayInner = 0, census0 = 0, census1 = 0, census2 = 0, census3 = 0;
+
+    bool haveRay = false;
+    int kind = 0;                 // 0: extension ray, 1: shadow ray
+    uint32_t index = 0;
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), invdir = mk3(0, 0, 0);
+    float distance = kFltMax;     // extension: closest hit so far; shadow: distance of the light
+    float hu = 0.0f, hv = 0.0f;
+    int hitRef = -1;              // extension: triangle record of the closest hit; shadow: >= 0 when occluded
+    int cur = kDone;
+    uint32_t qHead = 0, qCount = 0;
+    int ti = -1;
+
+    for (;;) {
+        const bool idle = (cur == kDone) && (qCount == 0) && (ti < 0);
+        const unsigned long long idleMask = __ballot(idle);
+        const int nIdle = __popcll(idleMask);
+        if (nIdle == 64 || (nIdle >= (int)p.tuneRefill && phase < 2)) { // wave-uniform
+            while (next >= end && phase < 2) { // next chunk of the current queue, or the first one of the next queue
+                uint32_t base = 0;
+                if ((threadIdx.x & 63) == 0) base = atomicAdd(&p.travCounters[phase], p.raysPerWave);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                const uint32_t count = phase == 0 ? countExt : countSh;
+                if (base < count) { next = base; end = (base + p.raysPerWave < count) ? base + p.raysPerWave : count; }
+                else { phase++; next = end = 0; }
+            }
+            if (idle) {
+                if (haveRay) {
+                    if (STATS && kind == 0) { atomicAdd(&p.stats->rayInnerHist[rayInner / 16u < 31u ? rayInner / 16u : 31u], 1ull); rayInner = 0; }
+                    if (kind == 0) {
+                        // finish the extension ray: extensionRayCast.hlsl:218-232
+                        if (distance < kFltMax) {
+                            st3(p, F_SP_X, index, o + d * distance);
+                            st3(p, F_BARY_X, index, mk3(1.0f - hu - hv, hu, hv));
+                            const int4 T = *reinterpret_cast<const int4*>(&p.scene.tris[hitRef]);
+                            stu(p, F_TRI_0, index, (uint32_t)T.x); stu(p, F_TRI_1, index, (uint32_t)T.y);
+                            stu(p, F_TRI_2, index, (uint32_t)T.z); stu(p, F_TRI_MAT, index, (uint32_t)T.w);
+                        }
+                        uint32_t lightIndex = 0;
+                        const uint32_t lc = p.cam.lightCount < GMUPT_MAX_LIGHTS ? p.cam.lightCount : GMUPT_MAX_LIGHTS;
+                        for (uint32_t li = 0; li < lc; li++) {
+                            const gmupt_light L = p.scene.lights[li];
+                            const f3 position = mk3(L.position[0], L.position[1], L.position[2]) - o;
+                            const float radius2 = L.radius * L.radius;
+                            const float tca = dot3(position, d);
+                            const float d2 = dot3(position, position) - tca * tca;
+                            if (d2 > radius2) continue;
+                            const float thc = dsqrt(radius2 - d2);
+                            float t0 = tca - thc;
+                            const float t1 = tca + thc;
+                            if (t0 < 0.0f) t0 = t1;
+                            if (t0 > 0.0f && t0 < distance) { distance = t0; lightIndex = li + 1; }
+                        }
+                        stu(p, F_IS_EMITTER, index, lightIndex);
+                        stf(p, F_HIT_DIST, index, distance);
+                    } else {
+                        stu(p, F_IN_SHADOW, index, hitRef >= 0 ? 1u : 0u);   // shadowRayCast.hlsl:167
+                    }
+                    haveRay = false;
+                }
+                const uint32_t my = next + prefix_rank(idleMask);
+                if (my < end) {
+                    if (phase == 0) { // wave-uniform
+                        index = qExt[my];                                    // extensionRayCast.hlsl:210
+                        if (index != kQueueHole) {
+                            haveRay = true; kind = 0;
+                            if (STATS) raysE++;
+                            o = ld3(p, F_RAY_OX, index); d = ld3(p, F_RAY_DX, index); // :213-214
+                            distance = kFltMax;
+                        }
+                    } else {
+                        index = qSh[my];                                     // shadowRayCast.hlsl:159
+                        haveRay = true; kind = 1;
+                        if (STATS) raysS++;
+                        o = ld3(p, F_SH_OX, index); d = ld3(p, F_SH_DX, index); // :162-163
+                        distance = ldf(p, F_LIGHT_DIST, index);              // :164
+                    }
+                    if (haveRay) {
+                        invdir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        hitRef = -1; hu = 0.0f; hv = 0.0f;
+                        stk.reset(); qHead = 0; qCount = 0; ti = -1;
+                        cur = (ray_box(ts.rootMin[0], ts.rootMin[1], ts.rootMin[2], ts.rootMax[0], ts.rootMax[1], ts.rootMax[2], o, invdir) > 0.0f) ? ts.rootDesc : kDone;
+                    }
+                }
+            }
+            if (nIdle == 64 && phase == 2) break; // nothing in flight and both queues are exhausted (wave-uniform)
+            next = (next + (uint32_t)nIdle < end) ? next + (uint32_t)nIdle : end;
+        }
+
+        if (STATS) { // lane census: where do the 64 lanes of a wave spend the loop iterations?
+            const bool pendingNow = (qCount > 0) || (ti >= 0);
+            census0 += __popcll(__ballot(cur == kDone && !pendingNow)); census1 += __popcll(__ballot(cur >= 0));
+            census2 += __popcll(__ballot(cur < 0 && cur != kDone)); census3 += __popcll(__ballot(cur == kDone && pendingNow));
+        }
+        // ---- REPS steps; a burst (wave-uniform, decided once per iteration) adds one triangle test per step to the lanes with leaves pending
+        const bool pendingNow = (qCount > 0) || (ti >= 0);
+        const int nPending = __popcll(__ballot(pendingNow));
+        const int nWalking = __popcll(__ballot(cur >= 0));
+        const bool burst = nPending >= (int)p.tuneTriThresh || (nWalking == 0 && nPending > 0); // wave-uniform
+#pragma unroll
+        for (int rep = 0; rep < REPS; rep++) {
+            // fetch phase
+            const bool doNode = cur >= 0;
+            vec4f na, nb, nc; vec2i nd;                      // defined for the doNode lanes only
+            if (doNode) load_node_buf<TOP>(rNodes, s_top, ts.topCount, cur, na, nb, nc, nd);
+            if (burst && ti < 0 && qCount > 0) { ti = fifo[(qHead & (kFifo - 1)) * kDefBlock]; qHead++; qCount--; }
+            const bool doTri = burst && ti >= 0;
+            vec4f r0, r1; vec2f r2;                          // defined for the doTri lanes only
+            if (doTri) tri_fetch_buf(rTris, ti, r0, r1, r2);
+            // compute phase
+            if (doNode) {
+                if (STATS) { if (kind == 0) { tcE.inner++; rayInner++; } else tcS.inner++; if (prefix_rank(__ballot(1)) == 0) { if (phase == 0) wInE++; else wInS++; } }
+                cur = inner_compute<OVF>(na, nb, nc, nd, o, invdir, stk, p.stats);
+            }
+            if (cur < 0 && cur != kDone && qCount < (uint32_t)kFifo) {
+                if (STATS) { if (kind == 0) tcE.leaves++; else tcS.leaves++; }
+                fifo[((qHead + qCount) & (kFifo - 1)) * kDefBlock] = ~cur;
+                qCount++;
+                cur = stk.pop();
+            }
+            if (doTri) {
+                if (STATS) { if (kind == 0) tcE.tris++; else tcS.tris++; if (prefix_rank(__ballot(1)) == 0) { if (phase == 0) wTrE++; else wTrS++; } }
+                float t = 0.0f, u = 0.0f, v = 0.0f; bool last;
+                if (tri_compute(make_float4(r0.x, r0.y, r0.z, r0.w), make_float4(r1.x, r1.y, r1.z, r1.w),
+                                make_float4(r2.x, r2.y, 0.0f, 0.0f), o, d, t, u, v, last)) {
+                    if (kind == 0) {
+                        if (t >= 0.0f && t < distance) { distance = t; hitRef = ti; hu = u; hv = v; } // extensionRayCast.hlsl:64-74
+                    } else {
+                        // shadowRayCast.hlsl:41-45,89: t in (1e-8, 1e8) and |d t| < lightDistance => occluded: the ray is decided
+                        if (t > kEpsilon && t < 1.0f / kEpsilon && length3(d * t) < distance) { hitRef = ti; last = true; qCount = 0; cur = kDone; }
+                    }
+                }
+                ti = last ? -1 : ti + 1;
+            }
+        }
+    }
+    if (STATS) { flush_counts(p.stats, tcE, raysE, true); flush_wave_iters(p.stats, wInE, wTrE, true);
+                 flush_counts(p.stats, tcS, raysS, false); flush_wave_iters(p.stats, wInS, wTrS, false);
+                 if ((threadIdx.x & 63) == 0) {
+                     const unsigned long long life = wall_clock64() - tStart;
+                     atomicAdd(&p.stats->castWaves, 1ull); atomicAdd(&p.stats->castWaveClocks, life); atomicMax(&p.stats->castWaveClocksMax, life);
+                     atomicAdd(&p.stats->castWaveEndHist[life / 5000ull < 31ull ? life / 5000ull : 31ull], 1ull);
+                     atomicAdd(&p.stats->laneCensus[0], (unsigned long long)census0); atomicAdd(&p.stats->laneCensus[1], (unsigned long long)census1);
+                     atomicAdd(&p.stats->laneCensus[2], (unsigned long long)census2); atomicAdd(&p.stats->laneCensus[3], (unsigned long long)census3);
+                 } }
+}
+
+
 // ------------------------------------------------------------------------------------------------ three-slot lane pipeline
 // Lane census of the kernels above (collect_stats): 29 % of the lanes have no ray (they wait for the next batched refill, whose
 // finish-and-fetch code and two dependent loads stall the whole wave), 14 % have finished walking and wait for their queued leaves.
@@ -826,7 +1060,10 @@ void launch_cast(const RenderParams& p, bool stats, int mode, hipStream_t s)
 {
     const uint32_t pb = p.travGridBlocks;
     const bool ovf = p.trav.maxDepth + 2 > (uint32_t)kDefStack;
-    if (mode == 60 && !p.extendPrune && !p.shadowPrune) GMUPT_DEF_LAUNCH(k_cast_m, true, 4, 4);
+    const bool plain = !p.extendPrune && !p.shadowPrune;   // the opt-in prunings exist in the separate bodies only
+    if (mode == 60 && plain) GMUPT_DEF_LAUNCH(k_cast_f, true, 6, 4);        // cast0 (default): mixed lanes, fused fetches
+    else if (mode == 62 && plain) GMUPT_DEF_LAUNCH(k_cast_m, true, 4, 4);   // cast2: mixed lanes, separate triangle bursts
+    else if (mode == 63 && plain) GMUPT_DEF_LAUNCH(k_cast_f, true, 4, 4);   // cast3: as cast0 with 4 steps per loop iteration
     else GMUPT_DEF_LAUNCH(k_cast_d, true, 4, 4);
 }
 

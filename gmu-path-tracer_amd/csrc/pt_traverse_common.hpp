@@ -35,11 +35,16 @@ __device__ __forceinline__ float ray_box_entry(float mnx, float mny, float mnz, 
     return (t1 >= t0) ? (t0 > 0.0f ? t0 : t1) : -1.0f;
 }
 
-// Moeller-Trumbore on a packed record (extensionRayCast.hlsl:38-62 == shadowRayCast.hlsl:16-40); returns false on a miss
-__device__ __forceinline__ bool tri_test(const Tri48* tris, int i, f3 o, f3 d, float& t, float& u, float& v, bool& last)
+// Moeller-Trumbore on a packed record (extensionRayCast.hlsl:38-62 == shadowRayCast.hlsl:16-40); returns false on a miss.
+// Split into the fetch and the arithmetic so that a kernel can issue the fetch ahead of other work.
+__device__ __forceinline__ void tri_fetch(const Tri48* tris, int i, float4& r0, float4& r1, float4& r2)
 {
     const float4* r = reinterpret_cast<const float4*>(tris + i);
-    const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+    r0 = r[0]; r1 = r[1]; r2 = r[2];
+}
+
+__device__ __forceinline__ bool tri_compute(const float4 r0, const float4 r1, const float4 r2, f3 o, f3 d, float& t, float& u, float& v, bool& last)
+{
     last = __builtin_bit_cast(uint32_t, r2.y) != 0u;
     const f3 v0 = mk3(r0.x, r0.y, r0.z), e1 = mk3(r0.w, r1.x, r1.y), e2 = mk3(r1.z, r1.w, r2.x);
     const f3 pvec = cross3(d, e2);
@@ -54,6 +59,13 @@ __device__ __forceinline__ bool tri_test(const Tri48* tris, int i, f3 o, f3 d, f
     if (v < 0.0f || u + v > 1.0f) return false;
     t = dot3(e2, qvec) * invDet;
     return true;
+}
+
+__device__ __forceinline__ bool tri_test(const Tri48* tris, int i, f3 o, f3 d, float& t, float& u, float& v, bool& last)
+{
+    float4 r0, r1, r2;
+    tri_fetch(tris, i, r0, r1, r2);
+    return tri_compute(r0, r1, r2, o, d, t, u, v, last);
 }
 
 __device__ __forceinline__ void flush_counts(DevStats* st, const TravCount& tc, uint32_t rays, bool ext)

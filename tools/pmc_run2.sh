@@ -11,5 +11,5 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU S
            "GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
   echo "pass $i: $set"
-  timeout -k 10 120 rocprofv3 --pmc $set --output-format csv -d $OUT/pass$i -- python3 bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-roofline > $OUT/pass$i.log 2>&1 || echo "pass $i failed"
+  timeout -k 10 120 rocprofv3 --pmc $set --output-format csv -d $OUT/pass$i -- python3 bench.py --prewarm 260 --steps 10 --warmup 5 --no-cpu-baseline --no-roofline > $OUT/pass$i.log 2>&1 || echo "pass $i failed"
 done
