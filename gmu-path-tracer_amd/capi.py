@@ -16,7 +16,7 @@ REF_GRID_THREADS = 34 * 8 * 256
 STATE_BYTES = 248
 
 (BUFFER_BVH_NODES, BUFFER_TRIANGLES, BUFFER_VERTICES, BUFFER_LIGHTS, BUFFER_TRI_PROPS, BUFFER_MATERIALS, BUFFER_TEXTURE_ARRAY) = range(7)
-STAGE_SHADE, STAGE_EXTEND, STAGE_SHADOW = range(3)
+STAGE_SHADE, STAGE_EXTEND, STAGE_SHADOW, STAGE_RAYCASTS = range(4)
 MATERIAL_UE4, MATERIAL_GLASS = 0, 1
 
 # numpy views of the reference PODs (sizes asserted below)

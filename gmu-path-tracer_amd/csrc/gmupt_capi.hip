@@ -542,6 +542,7 @@ extern "C" int gmupt_debug_run_stage(gmupt_renderer* r, gmupt_stage stage)
     case GMUPT_STAGE_SHADE: return run_iteration(r, true, false, false);
     case GMUPT_STAGE_EXTEND: return run_iteration(r, false, true, false);
     case GMUPT_STAGE_SHADOW: return run_iteration(r, false, false, true);
+    case GMUPT_STAGE_RAYCASTS: return run_iteration(r, false, true, true);
     }
     return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_debug_run_stage: unknown stage %d", (int)stage);
 }

@@ -647,6 +647,10 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_f(RenderParams p)
                 else { phase++; next = end = 0; }
             }
             if (idle) {
+#ifndef GMUPT_KNOCKOUT
+#define GMUPT_KNOCKOUT 0   // timing experiments only (tools/knockout.py; results are wrong): 1 no result stores, 3 no triangle tests
+#endif
+                if (haveRay && GMUPT_KNOCKOUT == 1) haveRay = false;
                 if (haveRay) {
                     if (STATS && kind == 0) { atomicAdd(&p.stats->rayInnerHist[rayInner / 16u < 31u ? rayInner / 16u : 31u], 1ull); rayInner = 0; }
                     if (kind == 0) {
@@ -734,7 +738,8 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_f(RenderParams p)
                 if (STATS) { if (kind == 0) { tcE.inner++; rayInner++; } else tcS.inner++; if (prefix_rank(__ballot(1)) == 0) { if (phase == 0) wInE++; else wInS++; } }
                 cur = inner_compute<OVF>(na, nb, nc, nd, o, invdir, stk, p.stats);
             }
-            if (cur < 0 && cur != kDone && qCount < (uint32_t)kFifo) {
+            if (GMUPT_KNOCKOUT == 3) { if (cur < 0 && cur != kDone) cur = stk.pop(); }
+            else if (cur < 0 && cur != kDone && qCount < (uint32_t)kFifo) {
                 if (STATS) { if (kind == 0) tcE.leaves++; else tcS.leaves++; }
                 fifo[((qHead + qCount) & (kFifo - 1)) * kDefBlock] = ~cur;
                 qCount++;

@@ -194,7 +194,8 @@ int gmupt_debug_read_queues(gmupt_renderer* r, uint32_t* dst, size_t bytes);    
 int gmupt_debug_write_queues(gmupt_renderer* r, const uint32_t* src, size_t bytes);
 int gmupt_debug_write_counters(gmupt_renderer* r, const uint32_t in[8]);
 int gmupt_debug_write_framebuffer(gmupt_renderer* r, const float* rgba, size_t bytes);
-typedef enum { GMUPT_STAGE_SHADE = 0 /* logic+newPath+materialUE4+materialGlass */, GMUPT_STAGE_EXTEND = 1, GMUPT_STAGE_SHADOW = 2 } gmupt_stage;
+typedef enum { GMUPT_STAGE_SHADE = 0 /* logic+newPath+materialUE4+materialGlass */, GMUPT_STAGE_EXTEND = 1, GMUPT_STAGE_SHADOW = 2,
+               GMUPT_STAGE_RAYCASTS = 3 /* both ray casts as gmupt_iterate launches them (one fused launch by default) */ } gmupt_stage;
 int gmupt_debug_run_stage(gmupt_renderer* r, gmupt_stage stage);
 /* evaluates the device copy of the deterministic math (fn: 0 sin, 1 cos, 2 log2, 3 exp2, 4 pow(x,y), 5 frac, 6 rng probe) */
 int gmupt_debug_detmath(gmupt_device* dev, int fn, const float* x, const float* y, float* out, uint32_t n);
