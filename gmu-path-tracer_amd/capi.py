@@ -59,6 +59,7 @@ class Stats(C.Structure):
                 ("ms_extend", C.c_double), ("ms_shadow", C.c_double), ("timed_iterations", C.c_uint64),
                 ("ext_wave_inner", C.c_uint64), ("ext_wave_tris", C.c_uint64), ("sh_wave_inner", C.c_uint64), ("sh_wave_tris", C.c_uint64), ("ext_depth_hist", C.c_uint64 * 32),
                 ("lane_census", C.c_uint64 * 4), ("cast_waves", C.c_uint64), ("cast_wave_ticks", C.c_uint64), ("cast_wave_ticks_max", C.c_uint64),
+                ("cast_drain_ticks", C.c_uint64), ("cast_drain_iters", C.c_uint64), ("cast_drain_busy_lanes", C.c_uint64),
                 ("cast_wave_end_hist", C.c_uint64 * 32), ("ray_inner_hist", C.c_uint64 * 32)]
 
     def as_dict(self):

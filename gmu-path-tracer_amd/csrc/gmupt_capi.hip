@@ -627,6 +627,7 @@ extern "C" int gmupt_get_stats(gmupt_renderer* r, gmupt_stats* out)
     for (int k = 0; k < 32; k++) { out->ext_depth_hist[k] = ds.extDepthHist[k]; out->cast_wave_end_hist[k] = ds.castWaveEndHist[k]; out->ray_inner_hist[k] = ds.rayInnerHist[k]; }
     for (int k = 0; k < 4; k++) out->lane_census[k] = ds.laneCensus[k];
     out->cast_waves = ds.castWaves; out->cast_wave_ticks = ds.castWaveClocks; out->cast_wave_ticks_max = ds.castWaveClocksMax;
+    out->cast_drain_ticks = ds.castDrainClocks; out->cast_drain_iters = ds.castDrainIters; out->cast_drain_busy_lanes = ds.castDrainBusyLanes;
     out->ext_wave_inner = ds.extWaveInner; out->ext_wave_tris = ds.extWaveTris; out->sh_wave_inner = ds.shWaveInner; out->sh_wave_tris = ds.shWaveTris;
     return GMUPT_OK;
 }

@@ -52,6 +52,7 @@ struct DevStats {
     // collect_stats, fused ray cast (k_cast_m) only:
     unsigned long long laneCensus[4];     // lane-iterations without a ray / walking / holding a leaf for a full FIFO / walk finished, leaves pending
     unsigned long long castWaves, castWaveClocks, castWaveClocksMax; // per-wave lifetime in 100 MHz ticks: sum and maximum
+    unsigned long long castDrainClocks, castDrainIters, castDrainBusyLanes; // after the wave found both queues empty: ticks, loop iterations, lanes with a ray summed over them
     unsigned long long castWaveEndHist[32]; // wave lifetimes in 50-us buckets (all waves of the persistent grid start together)
     unsigned long long rayInnerHist[32];    // extension rays by inner nodes visited, 16 per bucket
     uint32_t activePaths;

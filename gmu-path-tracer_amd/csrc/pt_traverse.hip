@@ -620,6 +620,7 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_f(RenderParams p)
     uint32_t next = 0, end = 0;
     int phase = 0;
     const unsigned long long tStart = STATS ? wall_clock64() : 0ull;
+    unsigned long long tDrain = 0ull; uint32_t drainIters = 0, drainBusy = 0;
     uint32_t rayInner = 0, census0 = 0, census1 = 0, census2 = 0, census3 = 0;
 
     bool haveRay = false;
@@ -715,6 +716,7 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_f(RenderParams p)
 
         if (STATS) { // lane census: where do the 64 lanes of a wave spend the loop iterations?
             const bool pendingNow = (qCount > 0) || (ti >= 0);
+            if (phase == 2) { if (tDrain == 0ull) tDrain = wall_clock64(); drainIters++; drainBusy += __popcll(__ballot(haveRay && !(cur == kDone && !pendingNow))); }
             census0 += __popcll(__ballot(cur == kDone && !pendingNow)); census1 += __popcll(__ballot(cur >= 0));
             census2 += __popcll(__ballot(cur < 0 && cur != kDone)); census3 += __popcll(__ballot(cur == kDone && pendingNow));
         }
@@ -764,7 +766,10 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_f(RenderParams p)
     if (STATS) { flush_counts(p.stats, tcE, raysE, true); flush_wave_iters(p.stats, wInE, wTrE, true);
                  flush_counts(p.stats, tcS, raysS, false); flush_wave_iters(p.stats, wInS, wTrS, false);
                  if ((threadIdx.x & 63) == 0) {
-                     const unsigned long long life = wall_clock64() - tStart;
+                     const unsigned long long tEnd = wall_clock64();
+                     const unsigned long long life = tEnd - tStart;
+                     atomicAdd(&p.stats->castDrainClocks, tDrain ? tEnd - tDrain : 0ull); atomicAdd(&p.stats->castDrainIters, (unsigned long long)drainIters);
+                     atomicAdd(&p.stats->castDrainBusyLanes, (unsigned long long)drainBusy);
                      atomicAdd(&p.stats->castWaves, 1ull); atomicAdd(&p.stats->castWaveClocks, life); atomicMax(&p.stats->castWaveClocksMax, life);
                      atomicAdd(&p.stats->castWaveEndHist[life / 5000ull < 31ull ? life / 5000ull : 31ull], 1ull);
                      atomicAdd(&p.stats->laneCensus[0], (unsigned long long)census0); atomicAdd(&p.stats->laneCensus[1], (unsigned long long)census1);

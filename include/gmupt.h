@@ -172,7 +172,8 @@ typedef struct {
     uint64_t ext_depth_hist[32]; /* inner-node visits of the extension rays by node depth */
     /* collect_stats with the fused ray cast (GMUPT_STAT_FUSED_CAST) only */
     uint64_t lane_census[4];          /* lane-iterations: no ray / walking / holding a leaf for a full FIFO / walk done, leaves pending */
-    uint64_t cast_waves, cast_wave_ticks, cast_wave_ticks_max; /* wave lifetimes in 100 MHz ticks: count, sum, maximum */
+    uint64_t cast_waves, cast_wave_ticks, cast_wave_ticks_max; /* wave lifetimes in wall-clock ticks: count, sum, maximum */
+    uint64_t cast_drain_ticks, cast_drain_iters, cast_drain_busy_lanes; /* after a wave found both queues empty: ticks, loop iterations, busy lanes summed over them */
     uint64_t cast_wave_end_hist[32];  /* wave lifetimes in 50-us buckets */
     uint64_t ray_inner_hist[32];      /* extension rays by inner nodes visited, 16 per bucket */
 } gmupt_stats;

@@ -17,6 +17,8 @@ print("lane census per loop iteration (idle, walking, stalled-with-full-FIFO, wa
 print("wave loop iterations per launch and wave:", h.sum() / 64 / max(st.cast_waves, 1))
 print("inner SIMD eff", st.ext_inner / max(64 * st.ext_wave_inner, 1), "tri SIMD eff", st.ext_tris / max(64 * st.ext_wave_tris, 1))
 print("waves per launch", st.cast_waves / N, "mean wave lifetime us", st.cast_wave_ticks / max(st.cast_waves, 1) / 100.0, "max us", st.cast_wave_ticks_max / 100.0)
+print("drain (both queues empty): fraction of the wave lifetime", st.cast_drain_ticks / max(st.cast_wave_ticks, 1), "loop iterations per wave", st.cast_drain_iters / max(st.cast_waves, 1),
+      "of", h.sum() / 64 / max(st.cast_waves, 1), "busy lanes per drain iteration", st.cast_drain_busy_lanes / max(st.cast_drain_iters, 1))
 print("wave lifetimes, 50-us buckets (per launch):", (np.array(list(st.cast_wave_end_hist)) / N).round(0).astype(int).tolist())
 rh = np.array(list(st.ray_inner_hist), dtype=np.float64)
 print("extension rays by inner nodes visited, 16 per bucket (fraction):", np.round(rh / max(rh.sum(), 1), 4).tolist())
