@@ -1071,9 +1071,10 @@ void launch_cast(const RenderParams& p, bool stats, int mode, hipStream_t s)
     const uint32_t pb = p.travGridBlocks;
     const bool ovf = p.trav.maxDepth + 2 > (uint32_t)kDefStack;
     const bool plain = !p.extendPrune && !p.shadowPrune;   // the opt-in prunings exist in the separate bodies only
-    if (mode == 60 && plain) GMUPT_DEF_LAUNCH(k_cast_f, true, 6, 4);        // cast0 (default): mixed lanes, fused fetches
-    else if (mode == 62 && plain) GMUPT_DEF_LAUNCH(k_cast_m, true, 4, 4);   // cast2: mixed lanes, separate triangle bursts
-    else if (mode == 63 && plain) GMUPT_DEF_LAUNCH(k_cast_f, true, 4, 4);   // cast3: as cast0 with 4 steps per loop iteration
+    // k_cast_f addresses nodes and triangle records with 32-bit byte offsets into buffer resources (< 2 GiB each: 33 M nodes, 44 M records)
+    const bool fits = (uint64_t)p.trav.triBase * 64ull < (1ull << 31) && ((uint64_t)p.scene.numTris + 1ull) * 48ull < (1ull << 31);
+    if (mode == 60 && plain && fits) GMUPT_DEF_LAUNCH(k_cast_f, true, 6, 4);   // cast0 (default): mixed lanes, fused fetches
+    else if ((mode == 62 || mode == 60 || mode == 63) && plain) { if (mode == 63 && fits) GMUPT_DEF_LAUNCH(k_cast_f, true, 4, 4); else GMUPT_DEF_LAUNCH(k_cast_m, true, 4, 4); } // cast2: mixed lanes, separate triangle bursts; cast3: cast0 with 4 steps per iteration
     else GMUPT_DEF_LAUNCH(k_cast_d, true, 4, 4);
 }
 

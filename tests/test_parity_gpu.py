@@ -73,6 +73,18 @@ def test_iteration_parity(pkg, device, cornell_scene, soup_scene, spheres_small_
     hip.close(); sb.close(); orc.close()
 
 
+@pytest.mark.parametrize("mode", ["ref", "static", "whilewhile", "ifif1", "top", "coop", "def0", "def1", "pipe0", "cast1", "cast2", "cast3"])
+def test_every_traversal_rung_gives_the_same_bits(pkg, device, soup_scene, monkeypatch, mode):
+    # the ladder of ray-cast kernels kept for A/B timing (GMUPT_TRAVERSAL): every rung against the oracle
+    monkeypatch.setenv("GMUPT_TRAVERSAL", mode)
+    W, H, P = 48, 27, 4096
+    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, soup_scene, W, H, P)
+    for it in range(14):
+        PU.step_both(orc, hip, ocam, hcam)
+    _assert_same(orc, hip, P, P, 14)
+    hip.close(); sb.close(); orc.close()
+
+
 def test_deep_tree_uses_stack_overflow_path(pkg, device):
     # tree depth ~30: deeper than the LDS part of the traversal stacks (and than the reference's unchecked 16 entries, Q23)
     scene = pkg.scenes.build_scene(pkg.scenes.deep_chain_mesh())
