@@ -662,11 +662,14 @@ extern "C" int gmupt_render_budget(gmupt_renderer* r, gmupt_camera* cam, uint32_
     *hostActive = 1;
     uint32_t k = 0;
     int rc = GMUPT_OK;
-    // Drain: stop when no slot is active any more -- or when the active count has not moved for 2048 iterations.  The reference
-    // has immortal paths: a NaN throughput survives `all(throughput <= 0)` and the Russian roulette test (logic.hlsl:237,251), and a
-    // path trapped inside closed geometry never meets a light, so a handful of slots can stay alive for ever (they just occupy pool
-    // slots in the reference's progressive loop).  2048 is ten times the ~201-bounce horizon of every healthy path.
-    uint32_t lastActive = 0xFFFFFFFFu, unchangedSince = 0;
+    // Drain: stop when no slot is active any more -- or kDrainHorizon iterations after the budget ran out.  A healthy path lives at most
+    // ~205 iterations (Russian roulette after 200 bounces, logic.hlsl:248-255), but the reference has paths that do not end that way:
+    // a throughput that overflowed to inf survives the roulette and becomes inf / inf = NaN (:251-254), a NaN throughput survives
+    // `all(throughput <= 0)` (:237), and such a path only ends when its ray happens to hit a light or leave the scene -- in the closed
+    // bench room their number halves every ~450 iterations (0.007 % of all paths; their sample is saturate(NaN) = 0).  In the
+    // reference's progressive loop they just occupy pool slots; a bounded job must cut them off.
+    constexpr uint32_t kDrainHorizon = 512;
+    uint32_t drainStart = 0xFFFFFFFFu;
     for (; k < max_iterations; k++) {
         cam->cam.update(0.0f);                       // Renderer::update -> Scene::update -> Camera::update (Renderer.cpp:158)
         rc = gmupt_set_camera(r, cam->cam.getBuffer());
@@ -677,8 +680,8 @@ extern "C" int gmupt_render_budget(gmupt_renderer* r, gmupt_camera* cam, uint32_
             if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
             if (e != hipSuccess) { rc = fail(GMUPT_ERR_HIP, "gmupt_render_budget: %s", hipGetErrorString(e)); break; }
             if (*hostActive == 0) { k++; break; }
-            if (*hostActive != lastActive) { lastActive = *hostActive; unchangedSince = k; }
-            else if (*hostActive < r->p.L && k - unchangedSince >= 2048u) { k++; break; } // only while draining (some slots already retired)
+            if (*hostActive < r->p.L && drainStart == 0xFFFFFFFFu) drainStart = k;     // the first slots have retired: the budget is spent
+            if (drainStart != 0xFFFFFFFFu && k - drainStart >= kDrainHorizon) { k++; break; }
         }
     }
     (void)hipHostFree(hostActive);

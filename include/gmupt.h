@@ -183,8 +183,9 @@ int gmupt_enable_timing(gmupt_renderer* r, int mode); /* hipEvent timing on the 
 
 /* render until path_budget paths have completed (desc.path_budget must be > 0).  Every frame does what the reference's
  * Window::loop does (Source/Window.cpp:86-87): Camera::update (new randomSeed pair, iterationCounter++), upload, iterate.
- * The drain check reads one device word every 8 iterations; the loop ends when no slot is active, or when the active count has not
- * changed for 2048 iterations (the reference's immortal NaN paths, see gmupt_stats.active_paths).  Returns the iterations run in *iters. */
+ * The drain check reads one device word every 8 iterations; the loop ends when no slot is active, or 512 iterations after the budget
+ * ran out (2.5 x the ~205-iteration life of a healthy path; what is still alive then are the reference's NaN-throughput paths, which
+ * end only when their ray happens to hit a light).  Returns the iterations run in *iters. */
 typedef struct gmupt_camera gmupt_camera;
 int gmupt_render_budget(gmupt_renderer* r, gmupt_camera* camera, uint32_t max_iterations, uint32_t* iters);
 
