@@ -13,7 +13,8 @@ Steady state needs care: the reference has no depth limit and kills paths by Rus
 completes paths in bursts with a period of 201 iterations (damping 0.55 per period).  The default pre-warm is ten periods
 (2010 iterations, ~4 s) and the default K is one period (201), which makes the value independent of the phase.
 With N GPUs the frame is split into N row bands (one private pipeline per rank, no data-path collective); the timed region
-ends with the RCCL gather of the tiles to rank 0.
+ends with the RCCL gather of the tiles to rank 0 (the assembled frame stays on rank 0's GPU: the metric excludes scene build / upload
+and the final host read-back).
 
 Prints ONE JSON line on rank 0 (see the task contract); `roofline` is for the dominant kernel (the ray-cast launch: extension + shadow rays in one persistent kernel) and
 `cpu_baseline` is the scalar CPU oracle timed on a bounded sample on this box (rank 0, N = 1 only).

@@ -69,6 +69,7 @@ class ProgressiveSession:
         if self.dist is not None and self.world > 1 and self.dist.get_backend() == "nccl":
             local = local.cuda()
         frame = tiles.gather_tiles(local, self.width, self.height, self.rank, self.world, self.dist if self.world > 1 else None)
+        frame = frame.cpu().numpy() if frame is not None else None
         self.previews += 1
         if frame is not None and self.on_preview is not None:
             self.on_preview(self.frames, frame)

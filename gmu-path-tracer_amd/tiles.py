@@ -33,20 +33,24 @@ def assemble(tiles, width, height, world_size):
 
 
 def gather_tiles(local_tile, width, height, rank, world_size, dist=None, device=None):
-    """Gathers the per-rank tiles on rank 0.  local_tile: torch tensor (rows, width, 4) float32 on `device`.
+    """Gathers the per-rank tiles on rank 0.  local_tile: torch tensor (rows, width, 4) float32.
 
-    Bands may differ by one row, so every rank pads to the largest band; rank 0 returns the assembled frame
-    (numpy, height x width x 4), other ranks return None.
+    Bands may differ by one row, so every rank pads to the largest band.  Rank 0 returns the assembled frame as a torch tensor
+    (height x width x 4) ON THE DEVICE OF THE TILES -- no host copy happens here, the read-back is the caller's business
+    (frame.cpu().numpy()); the other ranks return None.
     """
     import torch
     if world_size == 1 or dist is None:
-        return assemble([local_tile.cpu().numpy()], width, height, 1)
+        return local_tile.reshape(height, width, 4)
     bands = row_bands(height, world_size)
     max_rows = max(r for _, r in bands)
-    padded = torch.zeros((max_rows, width, 4), dtype=torch.float32, device=local_tile.device)
-    padded[:local_tile.shape[0]] = local_tile
+    if local_tile.shape[0] == max_rows:
+        padded = local_tile.contiguous()
+    else:
+        padded = torch.zeros((max_rows, width, 4), dtype=torch.float32, device=local_tile.device)
+        padded[:local_tile.shape[0]] = local_tile
     gathered = [torch.empty_like(padded) for _ in range(world_size)] if rank == 0 else None
     dist.gather(padded, gathered, dst=0)
     if rank != 0:
         return None
-    return assemble([g.cpu().numpy() for g in gathered], width, height, world_size)
+    return torch.cat([g[:rows] for g, (_, rows) in zip(gathered, bands)], dim=0)

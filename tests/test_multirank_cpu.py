@@ -37,7 +37,7 @@ def _worker(rank, world, port, W, H, P, iters, out_path):
     local = torch.from_numpy(orc.framebuffer().copy())
     frame = pkg.tiles.gather_tiles(local, W, H, rank, world, dist)
     if rank == 0:
-        np.save(out_path, frame)
+        np.save(out_path, frame.cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
 
