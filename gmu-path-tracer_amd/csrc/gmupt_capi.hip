@@ -293,7 +293,7 @@ extern "C" int gmupt_renderer_create(gmupt_device* dev, const gmupt_renderer_des
     r->travBlocks = (L + tb - 1) / tb;
     p.ovfStride = r->travBlocks * tb;
     if (p.ovfStride < deferred_block_threads()) p.ovfStride = deferred_block_threads();
-    { const char* rw = std::getenv("GMUPT_RAYS_PER_WAVE"); p.raysPerWave = rw ? (uint32_t)std::atoi(rw) : 128u; if (p.raysPerWave < 64) p.raysPerWave = 64; }
+    { const char* rw = std::getenv("GMUPT_RAYS_PER_WAVE"); p.raysPerWave = rw ? (uint32_t)std::atoi(rw) : 128u; if (p.raysPerWave < 64) p.raysPerWave = 64; if (r->travMode >= 60 && p.raysPerWave > 128) p.raysPerWave = 128; /* the fused kernel keeps a chunk in two registers per lane */ }
     { const char* wpc = std::getenv("GMUPT_WAVES_PER_CU"); const uint32_t w = wpc ? (uint32_t)std::atoi(wpc) : 16u; const uint32_t db = deferred_block_threads(); p.travGridBlocks = (uint32_t)dev->prop.multiProcessorCount * ((w * 64 + db - 1) / db); if (p.travGridBlocks * db > p.ovfStride) p.travGridBlocks = p.ovfStride / db; if (p.travGridBlocks == 0) p.travGridBlocks = 1; }
     { const char* ep = std::getenv("GMUPT_EXTEND_PRUNE"); p.extendPrune = ep ? (uint32_t)std::atoi(ep) : 0u; }
     { const char* sp = std::getenv("GMUPT_SHADOW_PRUNE"); p.shadowPrune = sp ? (uint32_t)std::atoi(sp) : 0u; }

@@ -618,6 +618,7 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_f(RenderParams p)
     const __amdgpu_buffer_rsrc_t rNodes = make_rsrc(ts.nodes, ts.triBase * 64u);              // ts.triBase = number of packed nodes
     const __amdgpu_buffer_rsrc_t rTris = make_rsrc(ts.tris, (p.scene.numTris + 1u) * 48u);    // + the sentinel record
     uint32_t next = 0, end = 0;
+    uint32_t chunkBase = 0, qe0 = kQueueHole, qe1 = kQueueHole;  // the current chunk of queue entries, lane l holds entries l and 64 + l
     int phase = 0;
     const unsigned long long tStart = STATS ? wall_clock64() : 0ull;
     unsigned long long tDrain = 0ull; uint32_t drainIters = 0, drainBusy = 0;
@@ -644,13 +645,36 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_f(RenderParams p)
                 if ((threadIdx.x & 63) == 0) base = atomicAdd(&p.travCounters[phase], p.raysPerWave);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                 const uint32_t count = phase == 0 ? countExt : countSh;
-                if (base < count) { next = base; end = (base + p.raysPerWave < count) ? base + p.raysPerWave : count; }
+                if (base < count) {
+                    next = base; end = (base + p.raysPerWave < count) ? base + p.raysPerWave : count;
+                    // the whole chunk of queue entries goes into two registers per lane (two coalesced loads): a refill then takes
+                    // its entry from a neighbour's register instead of starting with a dependent queue read
+                    chunkBase = base;
+                    const uint32_t* q = phase == 0 ? qExt : qSh;
+                    const uint32_t lane = threadIdx.x & 63u;
+                    qe0 = (base + lane < end) ? q[base + lane] : kQueueHole;
+                    qe1 = (base + 64u + lane < end) ? q[base + 64u + lane] : kQueueHole;
+                }
                 else { phase++; next = end = 0; }
             }
-            if (idle) {
 #ifndef GMUPT_KNOCKOUT
 #define GMUPT_KNOCKOUT 0   // timing experiments only (tools/knockout.py; results are wrong): 1 no result stores, 3 no triangle tests
 #endif
+            // queue entry of every idle lane, out of the chunk registers (all lanes execute the two shuffles: a lane that sits out
+            // would not lend its registers)
+            const uint32_t my = next + prefix_rank(idleMask);
+            const uint32_t entry = idle ? ((my - chunkBase) & 127u) : 0u;
+            const uint32_t entryLo = (uint32_t)__shfl((int)qe0, (int)(entry & 63u)), entryHi = (uint32_t)__shfl((int)qe1, (int)(entry & 63u));
+            if (idle) {
+                // the next ray first: its loads are in flight while the finished ray is written back
+                const bool take = my < end;
+                const uint32_t newIndex = take ? (entry < 64u ? entryLo : entryHi) : kQueueHole;   // extensionRayCast.hlsl:210 / shadowRayCast.hlsl:159
+                const bool newRay = take && (phase != 0 || newIndex != kQueueHole); // holes only exist in the extension queue
+                f3 newO = mk3(0, 0, 0), newD = mk3(0, 0, 1); float newDist = kFltMax;
+                if (newRay) {
+                    if (phase == 0) { newO = ld3(p, F_RAY_OX, newIndex); newD = ld3(p, F_RAY_DX, newIndex); }                 // :213-214
+                    else { newO = ld3(p, F_SH_OX, newIndex); newD = ld3(p, F_SH_DX, newIndex); newDist = ldf(p, F_LIGHT_DIST, newIndex); } // :162-164
+                }
                 if (haveRay && GMUPT_KNOCKOUT == 1) haveRay = false;
                 if (haveRay) {
                     if (STATS && kind == 0) { atomicAdd(&p.stats->rayInnerHist[rayInner / 16u < 31u ? rayInner / 16u : 31u], 1ull); rayInner = 0; }
@@ -685,29 +709,14 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_f(RenderParams p)
                     }
                     haveRay = false;
                 }
-                const uint32_t my = next + prefix_rank(idleMask);
-                if (my < end) {
-                    if (phase == 0) { // wave-uniform
-                        index = qExt[my];                                    // extensionRayCast.hlsl:210
-                        if (index != kQueueHole) {
-                            haveRay = true; kind = 0;
-                            if (STATS) raysE++;
-                            o = ld3(p, F_RAY_OX, index); d = ld3(p, F_RAY_DX, index); // :213-214
-                            distance = kFltMax;
-                        }
-                    } else {
-                        index = qSh[my];                                     // shadowRayCast.hlsl:159
-                        haveRay = true; kind = 1;
-                        if (STATS) raysS++;
-                        o = ld3(p, F_SH_OX, index); d = ld3(p, F_SH_DX, index); // :162-163
-                        distance = ldf(p, F_LIGHT_DIST, index);              // :164
-                    }
-                    if (haveRay) {
-                        invdir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                        hitRef = -1; hu = 0.0f; hv = 0.0f;
-                        stk.reset(); qHead = 0; qCount = 0; ti = -1;
-                        cur = (ray_box(ts.rootMin[0], ts.rootMin[1], ts.rootMin[2], ts.rootMax[0], ts.rootMax[1], ts.rootMax[2], o, invdir) > 0.0f) ? ts.rootDesc : kDone;
-                    }
+                if (newRay) {
+                    haveRay = true; kind = phase; index = newIndex;            // phase is 0 (extension) or 1 (shadow) here
+                    if (STATS) { if (phase == 0) raysE++; else raysS++; }
+                    o = newO; d = newD; distance = newDist;
+                    invdir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    hitRef = -1; hu = 0.0f; hv = 0.0f;
+                    stk.reset(); qHead = 0; qCount = 0; ti = -1;
+                    cur = (ray_box(ts.rootMin[0], ts.rootMin[1], ts.rootMin[2], ts.rootMax[0], ts.rootMax[1], ts.rootMax[2], o, invdir) > 0.0f) ? ts.rootDesc : kDone;
                 }
             }
             if (nIdle == 64 && phase == 2) break; // nothing in flight and both queues are exhausted (wave-uniform)
