@@ -599,8 +599,8 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_m(RenderParams p)
 
 // k_cast_m with the two fetches of a loop step issued together: when the wave is in a triangle burst, every step first issues the node
 // fetch of the walking lanes AND the triangle fetch of the lanes with a pending leaf, then does the slab tests and the triangle test.
-// A burst therefore costs no memory round trips of its own (4 per loop iteration instead of 8); what is tested, and in which order per
-// ray, is unchanged: leaves leave the per-lane FIFO in visit order.
+// A burst therefore costs no memory round trips of its own (REPS per loop iteration instead of REPS + BURST); what is tested, and in which
+// order per ray, is unchanged: leaves leave the per-lane FIFO in visit order.  BURST is unused here (one triangle record per step).
 template <bool STATS, bool OVF, bool TOP, int REPS, int BURST>
 __global__ __launch_bounds__(kDefBlock) void k_cast_f(RenderParams p)
 {
