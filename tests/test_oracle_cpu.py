@@ -327,6 +327,86 @@ def test_ue4_diffuse_lobe_is_cosine_distributed(oracle, pkg):
     orc.close()
 
 
+def _ue4_reference(N, V, L, base, metallic, roughness):
+    """float64 restatement of ue4Pdf / ue4Evaluate (materialUE4.hlsl:70-115, bsdf.h:8-20) as published formulas, written independently
+    of the oracle's C code: returns (pdf, eval)."""
+    N, V, L, base = (np.asarray(x, np.float64) for x in (N, V, L, base))
+    H = L + V; H = H / np.linalg.norm(H, axis=-1, keepdims=True)
+    ndh, vdh, ldh = (N * H).sum(-1), (V * H).sum(-1), (L * H).sum(-1)
+    ndl, ndv = (N * L).sum(-1), (N * V).sum(-1)
+    a = roughness * roughness
+    D = lambda x: a * a / (np.pi * (x * x * (a * a - 1.0) + 1.0) ** 2)
+    pdf = (1.0 - metallic) * np.abs(ndl) / np.pi + metallic * D(np.abs(ndh)) * np.abs(ndh) / (4.0 * np.abs(vdh))
+    k = (roughness + 1.0) ** 2 / 8.0
+    Gs = lambda x: x / (x * (1.0 - k) + k)
+    spec = 0.037 + (base - 0.037) * metallic[..., None]
+    fc = (1.0 - ldh) ** 5
+    F = (1.0 - fc)[..., None] * spec + fc[..., None]
+    ev = base / np.pi * (1.0 - metallic)[..., None] + (D(ndh) * Gs(ndl) * Gs(ndv) / (4.0 * ndl * ndv))[..., None] * F
+    ev = np.where(((ndl <= 0) | (ndv <= 0))[..., None], 0.0, ev)
+    return pdf, ev
+
+
+def test_ue4_weight_and_direct_light_match_the_published_formulas(oracle, pkg):
+    # For random materials / view directions: the direction the stage sampled (whatever lobe it chose) must carry the weight
+    # eval(L) |N.L| / pdf(L) (materialUE4.hlsl:148-151), and the NEE term must be powerHeuristic(lightPdf, bsdfPdf) eval(lightDir) emission
+    # lightCount falloff (:184-188, bsdf.h:22-31) -- both against a float64 evaluation of the formulas, independent of the C restatement.
+    scene = pkg.scenes.build_scene(pkg.scenes.cornell_mesh())
+    P = 8192
+    orc, cam = _craft(oracle, scene, P)
+    rng = np.random.default_rng(11)
+    n = np.array([0.0, 0.0, 1.0])
+    th = rng.uniform(0.05, 1.45, P); ph = rng.uniform(0, 2 * np.pi, P)
+    V = np.stack([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)], axis=1)          # towards the viewer, upper hemisphere
+    base = rng.uniform(0.05, 0.95, (P, 3)); metallic = rng.uniform(0.0, 1.0, P); rough = rng.uniform(0.05, 1.0, P)
+    tl = rng.uniform(0.05, 1.4, P); pl = rng.uniform(0, 2 * np.pi, P)
+    Ldir = np.stack([np.sin(tl) * np.cos(pl), np.sin(tl) * np.sin(pl), np.cos(tl)], axis=1)       # unit direction to the light sample
+    dist = rng.uniform(2.0, 9.0, P).astype(np.float32)
+    w = orc.path_state().view(np.float32)
+    w[4 * P:8 * P].reshape(P, 4)[:, :3] = (-V).astype(np.float32)                                 # rayDirection = -V
+    w[14 * P:18 * P].reshape(P, 4)[:, :3] = n.astype(np.float32)
+    w[8 * P:12 * P].reshape(P, 4)[:, :3] = base.astype(np.float32)
+    w[12 * P:14 * P].reshape(P, 2)[:] = np.stack([metallic, rough], axis=1).astype(np.float32)
+    w[35 * P:39 * P].reshape(P, 4)[:, :3] = Ldir.astype(np.float32)                               # shadowrayDirection (offset 140 B)
+    st8 = orc.path_state()
+    oracle.state_field(st8, P, "lightIndex")[:, 0] = 0
+    oracle.state_field(st8, P, "lightDistance").view(np.float32)[:, 0] = dist
+    orc.queues()[1][:] = np.arange(P, dtype=np.uint32)
+    qc = orc.counters(); qc[2] = P; qc[4] = 0; qc[6] = 0
+    # what the stage actually read (binary32 values), for the float64 model
+    V32 = -oracle.state_field(st8, P, "rayDirection").view(np.float32).astype(np.float64)
+    base32 = oracle.state_field(st8, P, "matColor").view(np.float32).astype(np.float64)
+    mr32 = oracle.state_field(st8, P, "matMR").view(np.float32).astype(np.float64)
+    L32 = oracle.state_field(st8, P, "shadowrayDirection").view(np.float32).astype(np.float64)
+    orc.stage("material_ue4")
+    st = orc.path_state()
+    Ls = oracle.state_field(st, P, "rayDirection").view(np.float32).astype(np.float64)          # sampled direction
+    lt = oracle.state_field(st, P, "lightThroughput").view(np.float32).astype(np.float64)
+    N = np.broadcast_to(n, (P, 3))
+    pdf, ev = _ue4_reference(N, V32, Ls, base32, mr32[:, 0], mr32[:, 1])
+    ndl = (N * Ls).sum(-1)
+    want = np.where((pdf > 0)[:, None], ev * np.abs(ndl)[:, None] / pdf[:, None], 0.0)
+    good = (ndl > 0.02) & (pdf > 1e-3)                                                           # away from the grazing / tiny-pdf corner where float32 cancels
+    assert good.mean() > 0.8
+    rel = np.abs(lt[good] - want[good]) / np.maximum(np.abs(want[good]), 1e-3)
+    assert rel.max() < 2e-4, rel.max()                                                           # measured: 3e-5
+    assert np.all(lt[ndl <= 0] == 0.0)                                                            # below the horizon: eval = 0
+    assert (metallic[good] > 0.5).sum() > 1000 and (Ls[:, 2] > 0).mean() > 0.7                    # both lobes were exercised
+    # NEE: every slot has dot(lightDir, N) > 0, so every slot pushes a shadow ray and stores directLight
+    assert orc.counters()[6] == P
+    dl = oracle.state_field(st, P, "directLight").view(np.float32).astype(np.float64)
+    light = scene["lights"][0]
+    d64 = dist.astype(np.float64)
+    light_pdf = d64 * d64 / (4.0 * np.pi * float(light["radius"]) ** 2)
+    bsdf_pdf, ev_l = _ue4_reference(N, V32, L32, base32, mr32[:, 0], mr32[:, 1])
+    mis = light_pdf ** 2 / (bsdf_pdf ** 2 + light_pdf ** 2)                                      # powerHeuristic(lightPdf, bsdfPdf), bsdf.h:28-31
+    fall = np.clip(1.0 - (d64 / float(light["falloff"])) ** 4, 0.0, 1.0) ** 2 / (d64 * d64 + 1.0)
+    want_dl = (mis * fall)[:, None] * ev_l * np.asarray(light["emission"], np.float64)[None, :] * float(cam.buffer.lightCount)
+    rel = np.abs(dl - want_dl) / np.maximum(np.abs(want_dl), 1e-4)
+    assert rel.max() < 2e-3, rel.max()
+    orc.close()
+
+
 def test_glass_refraction_obeys_snell(oracle, pkg):
     # materialGlass.hlsl:23-46: entering glass (n = 1.458) a transmitted ray satisfies sin(t) = sin(i) / 1.458 and stays in the plane of
     # incidence; with the reference's Schlick term (r0 - (1 - r0) m^5 <= 0.035, quirk Q12) almost every ray is transmitted
