@@ -407,6 +407,93 @@ def test_ue4_weight_and_direct_light_match_the_published_formulas(oracle, pkg):
     orc.close()
 
 
+def test_logic_end_of_path_and_accumulation_formulas(oracle, pkg):
+    # logic.hlsl:200-262 + endPath :33-77 on crafted slots, one per pixel, against float64 formulas: (a) emitter hit adds the NORMALISED
+    # emission times throughput and drops the pending NEE (Q6); (b) a miss adds directLight (if not in shadow) and throughput' * envColor;
+    # (c) zero throughput ends without the environment term.  Ended paths are tonemapped per sample (saturate, x/(x+1), pow 1/2.2) and
+    # averaged into the pixel with the sample count kept as uint bits in alpha (Q4).
+    scene = pkg.scenes.build_scene(pkg.scenes.cornell_mesh())
+    W = H = 16; P = W * H
+    orc, cam = _craft(oracle, scene, P, W, H)
+    rng = np.random.default_rng(5)
+    st = orc.path_state()
+    f = lambda name: oracle.state_field(st, P, name)
+    rad = rng.uniform(0.0, 0.6, (P, 3)).astype(np.float32); thr = rng.uniform(0.1, 1.2, (P, 3)).astype(np.float32)
+    dl = rng.uniform(0.0, 0.8, (P, 3)).astype(np.float32); lthr = rng.uniform(0.2, 1.0, (P, 3)).astype(np.float32)
+    case = np.arange(P) % 4                       # 0 emitter hit, 1 miss lit, 2 miss in shadow, 3 zero throughput
+    lthr[case == 3] = 0.0
+    f("radiance").view(np.float32)[:] = rad; f("throughput").view(np.float32)[:] = thr
+    f("directLight").view(np.float32)[:] = dl; f("lightThroughput").view(np.float32)[:] = lthr
+    f("isEmitter")[:, 0] = np.where(case == 0, 1 + (np.arange(P) // 4) % 2, 0)
+    f("inShadow")[:, 0] = np.where(case == 2, 1, 0)
+    f("hitDistance").view(np.float32)[:, 0] = np.where((case == 1) | (case == 2), np.float32(3.4028234663852886e38), np.float32(2.5))
+    f("pathLength")[:, 0] = 3
+    sc = f("screenCoord"); sc[:, 0] = np.arange(P) % W; sc[:, 1] = np.arange(P) // W
+    fb0 = orc.framebuffer(); fb0[...] = 0.0                                   # no samples yet: alpha bits = 0
+    orc.stage("logic")
+    fb = orc.framebuffer().copy()
+    env = np.array(list(cam.buffer.envColor)[:3], np.float64)
+    lights = scene["lights"]
+    want = np.zeros((P, 3))
+    for i in range(P):
+        r, t = rad[i].astype(np.float64), thr[i].astype(np.float64)
+        if case[i] == 0:
+            e = np.asarray(lights[(i // 4) % 2]["emission"], np.float64)
+            r = r + e / e.max() * t                                           # sampleLight :192-197
+        else:
+            if case[i] != 2:
+                r = r + dl[i].astype(np.float64) * t                          # :230-231
+            t = t * lthr[i].astype(np.float64)                                # :234
+            if case[i] in (1, 2):
+                r = r + t * env                                               # :241-245
+        r = np.clip(r, 0.0, 1.0); r = r / (r + 1.0); want[i] = r ** (1.0 / 2.2)
+    got = fb.reshape(P, 4)
+    assert np.all(got[:, 3].view(np.uint32) == 1), "every crafted path ended and was counted once"
+    assert np.abs(got[:, :3] - want).max() < 5e-6, np.abs(got[:, :3] - want).max()
+    assert got[:, :3].max() <= 0.5 ** (1.0 / 2.2) + 1e-6                        # the per-sample tonemap bounds a pixel by 0.73
+    assert orc.counters()[0] == P                                              # all of them went to the newPath queue
+    # a second sample lands as the running mean (pixel * n + r) / (n + 1)
+    st = orc.path_state()
+    oracle.state_field(st, P, "radiance").view(np.float32)[:] = 0.0
+    oracle.state_field(st, P, "throughput").view(np.float32)[:] = 0.0
+    oracle.state_field(st, P, "isEmitter")[:, 0] = 1
+    orc.counters()[0] = 0
+    orc.stage("logic")
+    fb2 = orc.framebuffer().reshape(P, 4)
+    assert np.all(fb2[:, 3].view(np.uint32) == 2) and np.abs(fb2[:, :3] - want / 2.0).max() < 5e-6
+    orc.close()
+
+
+def test_nee_setup_samples_the_light_sphere(oracle, cornell_scene):
+    # createShadowRay (logic.hlsl:135-163): a uniformly sampled point on the chosen light's sphere, seen from surfacePoint + normal * 1e-3;
+    # lightDistance is the distance to that point minus 1e-3.  Checked on the live slots of a running render.
+    W, H, P = 64, 36, 8192
+    orc = oracle.Renderer(cornell_scene, W, H, P)
+    cam = oracle.Camera(W, H); cam.set_pose(*cornell_scene["camera"]); cam.buffer.lightCount = cornell_scene["light_count"]
+    for _ in range(3):
+        cam.update(); orc.set_camera(cam.buffer); orc.iterate()
+    cam.update(); orc.set_camera(cam.buffer); orc.stage("logic")
+    qc = orc.counters(); live = orc.queues()[1][:int(qc[2])].astype(np.int64)          # slots that went on to the UE4 stage
+    assert live.size > 2000
+    st = orc.path_state()
+    g = lambda name: oracle.state_field(st, P, name)
+    so = g("shadowrayOrigin").view(np.float32).astype(np.float64)[live]; sd = g("shadowrayDirection").view(np.float32).astype(np.float64)[live]
+    sp = g("surfacePoint").view(np.float32).astype(np.float64)[live]; nrm = g("normal").view(np.float32).astype(np.float64)[live]
+    ld = g("lightDistance").view(np.float32).astype(np.float64)[live, 0]; li = g("lightIndex")[live, 0]
+    assert np.all(li < cornell_scene["light_count"]) and len(set(li.tolist())) == cornell_scene["light_count"]
+    assert np.abs(so - (sp + nrm * 1e-3)).max() < 2e-6 and np.abs(np.linalg.norm(sd, axis=1) - 1.0).max() < 1e-6
+    lights = cornell_scene["lights"]
+    lpos = np.array([lights[int(i)]["position"] for i in li], np.float64); lrad = np.array([lights[int(i)]["radius"] for i in li], np.float64)
+    pt = so + sd * (ld + 1e-3)[:, None]
+    rel = (pt - lpos) / lrad[:, None]
+    assert np.abs(np.linalg.norm(rel, axis=1) - 1.0).max() < 2e-4                          # on the sphere
+    # uniform on the sphere: z = 1 - 2 u has mean 0 and second moment 1/3; azimuth is uniform
+    assert abs(rel[:, 2].mean()) < 0.04 and abs((rel[:, 2] ** 2).mean() - 1.0 / 3.0) < 0.03
+    assert abs(np.cos(np.arctan2(rel[:, 1], rel[:, 0])).mean()) < 0.05
+    assert np.all(g("inShadow")[live, 0] == 1)                                             # pre-set every iteration (Q8)
+    orc.close()
+
+
 def test_glass_refraction_obeys_snell(oracle, pkg):
     # materialGlass.hlsl:23-46: entering glass (n = 1.458) a transmitted ray satisfies sin(t) = sin(i) / 1.458 and stays in the plane of
     # incidence; with the reference's Schlick term (r0 - (1 - r0) m^5 <= 0.035, quirk Q12) almost every ray is transmitted
