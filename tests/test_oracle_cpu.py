@@ -494,6 +494,40 @@ def test_nee_setup_samples_the_light_sphere(oracle, cornell_scene):
     orc.close()
 
 
+@pytest.mark.parametrize("which", ["spheres", "soup"])
+def test_material_fetch_interpolates_vertex_normals_and_reads_the_material_table(oracle, spheres_small_scene, soup_scene, which):
+    # setMaterialHitProperties (logic.hlsl:79-133) without textures: shading normal = barycentric blend of the three PER-VERTEX normals
+    # (not renormalised, Q10), material = materialProp[tri.w] with roughness clamped to >= 0.014, queue by material type.
+    scene = spheres_small_scene if which == "spheres" else soup_scene          # smooth vertex normals / a scene with glass
+    W, H, P = 64, 36, 8192
+    orc = oracle.Renderer(scene, W, H, P)
+    cam = oracle.Camera(W, H); cam.set_pose(*scene["camera"]); cam.buffer.lightCount = scene["light_count"]
+    for _ in range(3):
+        cam.update(); orc.set_camera(cam.buffer); orc.iterate()
+    cam.update(); orc.set_camera(cam.buffer); orc.stage("logic")
+    qc = orc.counters(); q = orc.queues()
+    ue4 = q[1][:int(qc[2])].astype(np.int64); glass = q[2][:int(qc[3])].astype(np.int64)
+    assert ue4.size > 1000 and (which == "spheres" or glass.size > 50)
+    st = orc.path_state()
+    g = lambda name: oracle.state_field(st, P, name)
+    props, mats = scene["props"], scene["materials"]
+    for slots, mtype in ((ue4, 0), (glass, 1)):
+        if slots.size == 0:
+            continue
+        tri = g("triangle")[slots].astype(np.int64); bary = g("baryCoord").view(np.float32).astype(np.float64)[slots]
+        n = sum(props["normal"][tri[:, k]].astype(np.float64) * bary[:, k:k + 1] for k in range(3))
+        got = g("normal").view(np.float32).astype(np.float64)[slots]
+        assert np.abs(got - n).max() < 2e-6
+        if which == "spheres" and slots.size:
+            assert np.abs(np.linalg.norm(got, axis=1) - 1.0).max() > 1e-4                  # blended normals are NOT renormalised
+        m = mats[tri[:, 3]]
+        assert np.all(m["materialType"] == mtype)
+        assert np.array_equal(g("matColor").view(np.float32)[slots], m["color"][:, :3])
+        mr = g("matMR").view(np.float32)[slots]
+        assert np.array_equal(mr[:, 0], m["metallic"]) and np.array_equal(mr[:, 1], np.maximum(np.float32(0.014), m["roughness"]))
+    orc.close()
+
+
 def test_glass_refraction_obeys_snell(oracle, pkg):
     # materialGlass.hlsl:23-46: entering glass (n = 1.458) a transmitted ray satisfies sin(t) = sin(i) / 1.458 and stays in the plane of
     # incidence; with the reference's Schlick term (r0 - (1 - r0) m^5 <= 0.035, quirk Q12) almost every ray is transmitted
