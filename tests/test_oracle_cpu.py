@@ -528,6 +528,45 @@ def test_material_fetch_interpolates_vertex_normals_and_reads_the_material_table
     orc.close()
 
 
+def test_russian_roulette_rule(oracle, pkg):
+    # logic.hlsl:248-255: only paths longer than 200 bounces play; they survive with probability min(1, p * 0.004), p = max(throughput),
+    # and the survivors' throughput is multiplied by 1 / p (Q9).  Crafted slots in four groups of p.
+    scene = pkg.scenes.build_scene(pkg.scenes.cornell_mesh())
+    P = 16384
+    orc, cam = _craft(oracle, scene, P)
+    st = orc.path_state()
+    f = lambda name: oracle.state_field(st, P, name)
+    groups = np.array([50.0, 125.0, 200.0, 300.0], np.float32)
+    pmax = groups[np.arange(P) % 4]
+    f("throughput").view(np.float32)[:] = pmax[:, None] * np.array([1.0, 0.5, 0.25], np.float32)
+    f("lightThroughput").view(np.float32)[:] = 1.0
+    f("radiance").view(np.float32)[:] = 0.0
+    f("isEmitter")[:, 0] = 0; f("inShadow")[:, 0] = 1
+    f("hitDistance").view(np.float32)[:, 0] = 2.5
+    f("pathLength")[:, 0] = np.where(np.arange(P) < P // 2, 201, 200)          # the second half is not long enough to play
+    f("triangle")[:] = np.array([0, 1, 2, 0], np.uint32)
+    f("baryCoord").view(np.float32)[:] = np.float32(1.0 / 3.0)
+    f("screenCoord")[:, 0] = np.arange(P) % 16; f("screenCoord")[:, 1] = (np.arange(P) // 16) % 16
+    orc.stage("logic")
+    qc = orc.counters(); q = orc.queues()
+    alive = np.zeros(P, bool)
+    alive[q[1][:int(qc[2])]] = True; alive[q[2][:int(qc[3])]] = True
+    assert alive[P // 2:].all(), "paths of length <= 200 never play"
+    st = orc.path_state()
+    thr = oracle.state_field(st, P, "throughput").view(np.float32)
+    for k, pv in enumerate(groups):
+        sel = (np.arange(P) % 4 == k) & (np.arange(P) < P // 2)
+        want = min(1.0, float(pv) * 0.004); n = int(sel.sum())
+        got = alive[sel].mean()
+        assert abs(got - want) < 4.0 * np.sqrt(max(want * (1 - want), 1e-4) / n) + 1e-9, (pv, got, want)
+        surv = sel & alive
+        assert np.abs(thr[surv] - np.array([1.0, 0.5, 0.25], np.float32)).max() < 1e-6          # throughput * (1 / p)
+    keep = np.arange(P) >= P // 2
+    assert np.array_equal(thr[keep], (pmax[keep, None] * np.array([1.0, 0.5, 0.25], np.float32)))   # untouched below the horizon
+    assert np.all(oracle.state_field(st, P, "pathLength")[alive, 0] == np.where(np.arange(P) < P // 2, 202, 201)[alive])
+    orc.close()
+
+
 def test_glass_refraction_obeys_snell(oracle, pkg):
     # materialGlass.hlsl:23-46: entering glass (n = 1.458) a transmitted ray satisfies sin(t) = sin(i) / 1.458 and stays in the plane of
     # incidence; with the reference's Schlick term (r0 - (1 - r0) m^5 <= 0.035, quirk Q12) almost every ray is transmitted
