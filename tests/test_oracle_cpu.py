@@ -180,6 +180,58 @@ def test_extension_stage_vs_brute_force(oracle, soup_scene):
     orc.close()
 
 
+def _brute_force_occluded(scene, o, d, light_dist):
+    """The shadow rule (shadowRayCast.hlsl:41-45,89) over ALL triangle references in float32: occluded iff some reference passes the
+    Moeller-Trumbore test with t in (1e-8, 1e8) and |d t| < lightDistance."""
+    f = np.float32
+    v = scene["verts"]; t = scene["tris"]["v"]
+    v0, v1, v2 = v[t[:, 0]], v[t[:, 1]], v[t[:, 2]]
+    e1, e2 = v1 - v0, v2 - v0
+    cross = lambda a, b: np.stack([a[..., 1] * b[..., 2] - a[..., 2] * b[..., 1], a[..., 2] * b[..., 0] - a[..., 0] * b[..., 2], a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]], -1)
+    dot = lambda a, b: (a[..., 0] * b[..., 0] + a[..., 1] * b[..., 1]) + a[..., 2] * b[..., 2]
+    out = np.zeros(o.shape[0], bool)
+    for r in range(o.shape[0]):
+        dd = np.broadcast_to(d[r], e2.shape); oo = o[r]
+        pvec = cross(dd, e2); det = dot(e1, pvec)
+        with np.errstate(all="ignore"):
+            inv = f(1.0) / det
+            tvec = oo - v0
+            u = dot(tvec, pvec) * inv
+            qvec = cross(tvec, e1)
+            vv = dot(dd, qvec) * inv
+            tt = dot(e2, qvec) * inv
+            dist = np.sqrt(dot(dd * tt[:, None], dd * tt[:, None]))
+        ok = ~((det > -1e-8) & (det < 1e-8)) & ~(u < 0) & ~(u > 1) & ~(vv < 0) & ~(u + vv > 1) & (tt > f(1e-8)) & (tt < f(1.0) / f(1e-8)) & (dist < light_dist[r])
+        out[r] = ok.any()
+    return out
+
+
+def test_shadow_stage_vs_brute_force(oracle, soup_scene):
+    P = 512
+    orc = oracle.Renderer(soup_scene, 16, 16, P)
+    rng = np.random.default_rng(8)
+    o = rng.uniform(-10, 10, (P, 3)).astype(np.float32)
+    d = rng.normal(size=(P, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    ld = rng.uniform(0.5, 25.0, P).astype(np.float32)
+    st = orc.path_state()
+    oracle.state_field(st, P, "shadowrayOrigin").view(np.float32)[:] = o
+    oracle.state_field(st, P, "shadowrayDirection").view(np.float32)[:] = d
+    oracle.state_field(st, P, "lightDistance").view(np.float32)[:, 0] = ld
+    oracle.state_field(st, P, "inShadow")[:, 0] = 7                                     # must be overwritten with 0 / 1
+    orc.queues()[4][:] = np.arange(P, dtype=np.uint32)[::-1]                            # any order
+    qc = orc.counters(); qc[6] = P; qc[0] = 5; qc[1] = 11
+    cb = oracle.CameraBuffer(); cb.lightCount = 0; cb.pixelSize[0] = cb.pixelSize[1] = 1 / 16; cb.sampleCounter = 1
+    orc.set_camera(cb)
+    orc.stage("shadow")
+    got = oracle.state_field(orc.path_state(), P, "inShadow")[:, 0]
+    ref = _brute_force_occluded(soup_scene, o, d, ld)
+    assert 50 < ref.sum() < P - 50
+    assert np.array_equal(got, ref.astype(np.uint32)), "any-hit traversal must agree with the brute-force shadow rule"
+    qc = orc.counters()
+    assert (qc[0], qc[1], qc[2], qc[3]) == (0, 16, 0, 0)                               # counter hand-over of shadowRayCast.hlsl:144-148
+    orc.close()
+
+
 def test_tile_render_equals_full_frame_mapping(oracle, cornell_scene):
     # a tile-parameterised run maps path k to pixel (x0 + k % w, y0 + k / w) of the tile and shoots the same primary ray
     # the full frame would shoot through that pixel with the same queue index
