@@ -138,6 +138,23 @@ __device__ __forceinline__ int inner_compute(const vec4f a, const vec4f b, const
     return stk.pop();
 }
 
+// inner_compute with the choice written as selects around the two stack operations (same tests, same order of visits)
+template <bool OVF>
+__device__ __forceinline__ int inner_compute_flat(const vec4f a, const vec4f b, const vec4f c, const vec2i d, f3 o, f3 invdir, DefStack<OVF>& stk, DevStats* dst)
+{
+    const float leftHit = ray_box(a.x, a.y, a.z, a.w, b.x, b.y, o, invdir);
+    const float rightHit = ray_box(b.z, b.w, c.x, c.y, c.z, c.w, o, invdir);
+    const bool l = leftHit > 0.0f, r = rightHit > 0.0f;
+    const bool swap = leftHit > rightHit;            // extensionRayCast.hlsl:136: nearer child first, the other one deferred
+    const bool both = l && r;
+    const int nearChild = (both && swap) || (!l) ? d.y : d.x;   // both: nearer first; one: the hit one
+    const int farChild = swap ? d.x : d.y;
+    if (both) stk.push(farChild, dst);
+    int next = nearChild;
+    if (!(l | r)) next = stk.pop();
+    return next;
+}
+
 template <bool OVF, bool TOP>
 __device__ __forceinline__ int inner_step_d(const TravScene& ts, const float4* s_top, int cur, f3 o, f3 invdir, DefStack<OVF>& stk, DevStats* dst)
 {
@@ -747,7 +764,7 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_f(RenderParams p)
             // compute phase
             if (doNode) {
                 if (STATS) { if (kind == 0) { tcE.inner++; rayInner++; } else tcS.inner++; if (prefix_rank(__ballot(1)) == 0) { if (phase == 0) wInE++; else wInS++; } }
-                cur = inner_compute<OVF>(na, nb, nc, nd, o, invdir, stk, p.stats);
+                cur = inner_compute_flat<OVF>(na, nb, nc, nd, o, invdir, stk, p.stats);
             }
             if (GMUPT_KNOCKOUT == 3) { if (cur < 0 && cur != kDone) cur = stk.pop(); }
             else if (cur < 0 && cur != kDone && qCount < (uint32_t)kFifo) {
@@ -759,8 +776,8 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_f(RenderParams p)
             if (doTri) {
                 if (STATS) { if (kind == 0) tcE.tris++; else tcS.tris++; if (prefix_rank(__ballot(1)) == 0) { if (phase == 0) wTrE++; else wTrS++; } }
                 float t = 0.0f, u = 0.0f, v = 0.0f; bool last;
-                if (tri_compute(make_float4(r0.x, r0.y, r0.z, r0.w), make_float4(r1.x, r1.y, r1.z, r1.w),
-                                make_float4(r2.x, r2.y, 0.0f, 0.0f), o, d, t, u, v, last)) {
+                if (tri_compute_flat(make_float4(r0.x, r0.y, r0.z, r0.w), make_float4(r1.x, r1.y, r1.z, r1.w),
+                                     make_float4(r2.x, r2.y, 0.0f, 0.0f), o, d, t, u, v, last)) {
                     if (kind == 0) {
                         if (t >= 0.0f && t < distance) { distance = t; hitRef = ti; hu = u; hv = v; } // extensionRayCast.hlsl:64-74
                     } else {

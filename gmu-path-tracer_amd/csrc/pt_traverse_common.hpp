@@ -61,6 +61,24 @@ __device__ __forceinline__ bool tri_compute(const float4 r0, const float4 r1, co
     return true;
 }
 
+// the same test without early exits: every lane does all the arithmetic and the rejections become one predicate (identical results:
+// the same operations in the same order, the same comparisons; a lane that would have left early just carries values nobody reads)
+__device__ __forceinline__ bool tri_compute_flat(const float4 r0, const float4 r1, const float4 r2, f3 o, f3 d, float& t, float& u, float& v, bool& last)
+{
+    last = __builtin_bit_cast(uint32_t, r2.y) != 0u;
+    const f3 v0 = mk3(r0.x, r0.y, r0.z), e1 = mk3(r0.w, r1.x, r1.y), e2 = mk3(r1.z, r1.w, r2.x);
+    const f3 pvec = cross3(d, e2);
+    const float det = dot3(e1, pvec);
+    const float invDet = 1.0f / det;
+    const f3 tvec = o - v0;
+    u = dot3(tvec, pvec) * invDet;
+    const f3 qvec = cross3(tvec, e1);
+    v = dot3(d, qvec) * invDet;
+    t = dot3(e2, qvec) * invDet;
+    const bool rejected = (det > -kEpsilon && det < kEpsilon) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f);
+    return !rejected;
+}
+
 __device__ __forceinline__ bool tri_test(const Tri48* tris, int i, f3 o, f3 d, float& t, float& u, float& v, bool& last)
 {
     float4 r0, r1, r2;
