@@ -76,3 +76,25 @@ def test_bench_scene_long_run_bitwise(pkg, device, big_scene):
     pl = O.state_field(orc.path_state(), Pm, "pathLength")
     assert int(pl.max()) > 150
     hip.close(); sb.close(); orc.close()
+
+
+def test_config2_cornell_720p_reference_constants_bitwise(pkg, device, cornell_scene):
+    # BASELINE config 2 at its real size: Cornell box (34 triangles), 1280x720, the reference's PATHCOUNT = 2^21 with only
+    # ITERATIONS * NUM_GROUPS * NUM_THREADS = 2 088 960 live slots (quirk Q1), no tile (the literal uint(1 / pixelSize.x) width, exact at
+    # 1280), default camera and lights.  1 spp needs 921 600 paths: frame 0 starts 2 088 960 of them, so the first iterations carry
+    # more than one sample per pixel; four iterations are compared bit for bit (state, queues, counters, framebuffer).
+    W, H, P, L = 1280, 720, 1 << 21, 2088960
+    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, cornell_scene, W, H, P, live=L, threads=16)
+    for it in range(4):
+        PU.step_both(orc, hip, ocam, hcam)
+        if it in (0, 3):
+            bad = PU.compare_state(orc, hip, P, L)
+            assert not bad, "iteration %d: %r" % (it, bad[:3])
+            assert np.array_equal(orc.counters(), hip.counters())
+    fa, fb = orc.framebuffer(), hip.framebuffer()
+    assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32))
+    n_ext = int(orc.counters()[7])
+    assert np.array_equal(orc.queues()[3][:n_ext], hip.read_queues()[3][:n_ext])
+    spp = fb[..., 3].view(np.uint32)
+    assert spp.sum() > 0 and hip.counters()[1] >= L          # lastPathCnt advanced by PATHCOUNT on the clear frame and by the regenerated paths since
+    hip.close(); sb.close(); orc.close()
