@@ -120,3 +120,29 @@ def test_texture_array_from_png_resizes_to_the_common_size(pkg):
     assert np.array_equal(arr[1], b) and np.array_equal(arr[2], c) and np.array_equal(arr[0], pkg.capi.resize_square(a, 32))
     with pytest.raises(pkg.capi.GmuptError, match="square"):
         pkg.capi.texture_array_from_png([pkg.scenes.encode_png_rgba8(np.zeros((4, 8, 4), np.uint8))])
+
+
+def test_png_decoder_random_images_property(pkg):
+    # property test: any image our spec-level encoder can write (random size, colour type, depth, filters per row, interlace, IDAT
+    # split, compression level) decodes to the RGBA8 image the conversion rules give
+    from hypothesis import given, settings, strategies as st
+
+    formats = [(0, 1), (0, 2), (0, 4), (0, 8), (0, 16), (2, 8), (2, 16), (3, 1), (3, 2), (3, 4), (3, 8), (4, 8), (4, 16), (6, 8), (6, 16)]
+
+    @settings(max_examples=120, deadline=None)
+    @given(st.integers(0, len(formats) - 1), st.integers(1, 19), st.integers(1, 19), st.booleans(), st.integers(0, 2 ** 31 - 1),
+           st.lists(st.integers(0, 4), min_size=1, max_size=5), st.sampled_from([0, 1, 6, 9]), st.sampled_from([0, 1, 7, 64]))
+    def check(fmt, w, h, interlace, seed, filters, level, split):
+        color_type, depth = formats[fmt]
+        rng = np.random.default_rng(seed)
+        ch = png_util.CHANNELS[color_type]
+        samples = rng.integers(0, 1 << depth, (h, w, ch))
+        palette = rng.integers(0, 256, ((1 << depth), 3)) if color_type == 3 else None
+        trns = bytes(rng.integers(0, 256, 1 << depth).astype(np.uint8))[: int(rng.integers(0, (1 << depth) + 1))] if color_type == 3 else None
+        if trns is not None and len(trns) == 0:
+            trns = None
+        data = png_util.encode(samples, color_type, depth, filters=tuple(filters), interlace=interlace, palette=palette, trns=trns, level=level, idat_split=split)
+        got = pkg.capi.decode_png(data)
+        assert np.array_equal(got, png_util.expected_rgba(samples, color_type, depth, palette, trns))
+
+    check()
