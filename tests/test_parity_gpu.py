@@ -263,6 +263,51 @@ def test_stage_level_parity_from_frozen_state(pkg, device, spheres_small_scene):
     hip.close(); sb.close(); orc.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_ray_casts_on_grid_meshes_with_exact_ties(pkg, device, seed):
+    # adversarial geometry for the closest-hit rule: triangles on a coarse integer grid (coplanar duplicates, shared edges and vertices,
+    # degenerate triangles) and rays that start on grid points and run along grid directions, so that many hits have EXACTLY equal t
+    # and the winner is decided by the order of the tests (strict `t < distance`, extensionRayCast.hlsl:64-74) -- every rung of the
+    # default path (fused launch via STAGE_RAYCASTS, separate launches via STAGE_EXTEND / STAGE_SHADOW) against the oracle, bit for bit
+    rng = np.random.default_rng(seed)
+    n_tris = int(rng.integers(20, 400))
+    grid = int(rng.choice([3, 5, 9]))
+    nv = max(4, n_tris // 2)
+    verts = (rng.integers(0, grid, (nv, 3)) * (8.0 / (grid - 1)) - 4.0).astype(np.float32)
+    idx = rng.integers(0, nv, (n_tris, 3)).astype(np.int32)
+    idx[: n_tris // 5] = idx[n_tris // 5: 2 * (n_tris // 5)][: n_tris // 5]          # exact duplicates of other triangles
+    mesh = pkg.scenes.cornell_mesh()
+    normals = np.tile(np.array([0.0, 1.0, 0.0], np.float32), (nv, 1))
+    mesh.update({"verts": verts, "normals": normals, "indices": idx, "vertex_material": (rng.integers(0, 3, nv)).astype(np.uint32), "name": "grid%d" % seed})
+    mesh.pop("uv", None)
+    scene = pkg.scenes.build_scene(mesh)
+    P = 4096
+    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, scene, 32, 18, P)
+    pts = (rng.integers(0, grid, (P, 3)) * (8.0 / (grid - 1)) - 4.0).astype(np.float32)
+    dirs = rng.integers(-2, 3, (P, 3)).astype(np.float32); dirs[(dirs == 0).all(axis=1)] = (1.0, 0.0, 0.0)
+    dirs[: P // 2] /= np.linalg.norm(dirs[: P // 2], axis=1, keepdims=True)             # half of them normalised, half with integer components
+    o = (pts - dirs * rng.integers(1, 4, (P, 1)).astype(np.float32)).astype(np.float32)
+    st = orc.path_state()
+    O.state_field(st, P, "rayOrigin").view(np.float32)[:] = o; O.state_field(st, P, "rayDirection").view(np.float32)[:] = dirs
+    O.state_field(st, P, "shadowrayOrigin").view(np.float32)[:] = o; O.state_field(st, P, "shadowrayDirection").view(np.float32)[:] = dirs
+    O.state_field(st, P, "lightDistance").view(np.float32)[:, 0] = rng.uniform(0.5, 12.0, P).astype(np.float32)
+    orc.queues()[3][:] = np.arange(P, dtype=np.uint32); orc.queues()[4][:] = np.arange(P, dtype=np.uint32)[::-1]
+    qc = orc.counters(); qc[:] = 0; qc[6] = P; qc[7] = P
+    ocam.update(); hcam.update(0.0); orc.set_camera(ocam.buffer); hip.set_camera(hcam.buffer)
+    frozen = (orc.path_state().copy(), orc.queues().copy(), orc.counters().copy())
+    orc.stage("extension"); orc.stage("shadow")
+    fields = ["surfacePoint", "baryCoord", "triangle", "isEmitter", "hitDistance", "inShadow"]
+    hits = O.state_field(orc.path_state(), P, "hitDistance").view(np.float32)[:, 0]
+    assert (hits < 3e38).sum() > P // 20
+    for stages in ((pkg.capi.STAGE_RAYCASTS,), (pkg.capi.STAGE_EXTEND, pkg.capi.STAGE_SHADOW)):
+        hip.write_path_state(frozen[0]); hip.write_queues(frozen[1]); hip.write_counters(frozen[2])
+        for sname in stages:
+            hip.run_stage(sname)
+        bad = PU.compare_state(orc, hip, P, P, fields=fields)
+        assert not bad, (stages, bad[:3])
+    hip.close(); sb.close(); orc.close()
+
+
 def test_camera_reset_resize_and_light_update(pkg, device, cornell_scene):
     W, H, P = 32, 18, 1024
     orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, cornell_scene, W, H, P)
