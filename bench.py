@@ -232,7 +232,7 @@ def run_cpu_baseline(scene, W, H, args):
     s = orc.stats()
     orc.close()
     return {"value": round(s.pathsEnded / dt / 1e6, 5), "unit": "Mpaths/s", "cores": threads, "kind": "port",
-            "sample": "oracle (scalar C port of the six stages), pool %d, %d timed iterations = one completion period (%.1f s) after %d pre-warm iterations (%.1f s), same scene / resolution / camera; ray casts on %d OpenMP threads, shading stages serial"
+            "sample": "oracle (scalar C port of the six stages), pool %d, %d timed iterations = one completion period (%.1f s) after %d pre-warm iterations (%.1f s), same scene / resolution / camera; all stages on %d OpenMP threads (per-slot work parallel, queue / framebuffer order applied serially)"
                       % (pool, args.cpu_iters, dt, args.cpu_prewarm, t1 - t0, threads),
             "msegments_per_s": round(s.segments / dt / 1e6, 3)}
 

@@ -70,6 +70,8 @@ struct orc_renderer {
     uint32_t qc[8];
     float* fb;
     uint8_t* retired; /* extension: slot retired by pathBudget */
+    uint8_t* scratchKind; /* per slot / queue item outcome of the parallel first pass of logic and materialUE4 */
+    float* scratchRad;    /* radiance of the paths ended in this iteration (3 per slot) */
     uint32_t activePaths;
     orc_stats stats;
 };
@@ -313,9 +315,16 @@ void orc_stage_logic(orc_renderer* r)
     uint32_t* qUE4 = qptr(r, Q_MAT_UE4);
     uint32_t* qGlass = qptr(r, Q_MAT_GLASS);
 
-    for (uint32_t index = 0; index < r->cfg.livePaths; index++) {        /* :212-214 */
+    /* Two passes with identical results: the per-slot work (everything that only touches the slot's own state) runs on all host
+     * cores; queue pushes and framebuffer updates follow serially in ascending slot order -- the canonical schedule. */
+    enum { K_SKIP = 0, K_ENDED = 1, K_UE4 = 2, K_GLASS = 3, K_OTHER = 4 };
+    const int nthreads = r->cfg.threads > 1 ? (int)r->cfg.threads : 1;
+    const int64_t live = (int64_t)r->cfg.livePaths;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int64_t idx = 0; idx < live; idx++) {                           /* :212-214 */
+        const uint32_t index = (uint32_t)idx;
+        r->scratchKind[index] = K_SKIP;
         if (r->retired[index]) continue;                                 /* extension: pathBudget */
-        r->stats.segments++;
         rng_t g; rng_seed(&g, &r->cam, index);                           /* :216 */
         int pathEliminated = 0;                                          /* :217 */
         v3 throughput = ld3(r, F_THROUGHPUT, index);                     /* :219 */
@@ -344,15 +353,13 @@ void orc_stage_logic(orc_renderer* r)
             if (r->cfg.maxDepth && pl >= r->cfg.maxDepth) pathEliminated = 1; /* extension (config 5) */
         }
 
-        if (pathEliminated) {                                            /* :259 endPath */
-            accumulate_sample(r, radiance, index);
-            qNew[r->qc[QC_NEWPATH]++] = index;                           /* :75 */
-            r->stats.pathsEnded++;
+        if (pathEliminated) {                                            /* :259 endPath, applied in the second pass */
+            r->scratchKind[index] = K_ENDED;
+            r->scratchRad[3 * (size_t)index] = radiance.x; r->scratchRad[3 * (size_t)index + 1] = radiance.y; r->scratchRad[3 * (size_t)index + 2] = radiance.z;
             continue;
         }
         uint32_t materialType = set_material_hit_properties(r, index);   /* :262 */
-        if (materialType == 0) qUE4[r->qc[QC_MATUE4]++] = index;         /* :282-283 */
-        else if (materialType == 1) qGlass[r->qc[QC_MATGLASS]++] = index; /* :284-285 */
+        r->scratchKind[index] = materialType == 0 ? K_UE4 : (materialType == 1 ? K_GLASS : K_OTHER);
 
         create_shadow_ray(r, &g, index);                                 /* :291 */
         uint32_t pathLength = ld1u(r, F_PATH_LENGTH, index) + 1;         /* :293 */
@@ -360,6 +367,19 @@ void orc_stage_logic(orc_renderer* r)
         st3(r, F_THROUGHPUT, index, throughput);                         /* :296 */
         st1u(r, F_PATH_LENGTH, index, pathLength);                       /* :297 */
         st1u(r, F_INSHADOW, index, 1u);                                  /* :298 */
+    }
+    for (uint32_t index = 0; index < r->cfg.livePaths; index++) {        /* ascending slot order */
+        const uint8_t k = r->scratchKind[index];
+        if (k == K_SKIP) continue;
+        r->stats.segments++;
+        if (k == K_ENDED) {
+            const float* rad = r->scratchRad + 3 * (size_t)index;
+            accumulate_sample(r, V(rad[0], rad[1], rad[2]), index);      /* :49-73 */
+            qNew[r->qc[QC_NEWPATH]++] = index;                           /* :75 */
+            r->stats.pathsEnded++;
+        }
+        else if (k == K_UE4) qUE4[r->qc[QC_MATUE4]++] = index;           /* :282-283 */
+        else if (k == K_GLASS) qGlass[r->qc[QC_MATGLASS]++] = index;     /* :284-285 */
     }
 }
 
@@ -502,8 +522,12 @@ void orc_stage_material_ue4(orc_renderer* r) /* materialUE4.hlsl:118-192 */
     uint32_t* qExt = qptr(r, Q_EXT_RAY);
     uint32_t* qSh = qptr(r, Q_SHADOW_RAY);
 
-    for (uint32_t queueIndex = 0; queueIndex < r->cfg.livePaths; queueIndex++) { /* :125-129 */
-        if (queueIndex >= queueElementCount) break;
+    /* per-item work on all host cores; the shadow queue is then filled serially in ascending queue order (canonical schedule) */
+    const int nthreads = r->cfg.threads > 1 ? (int)r->cfg.threads : 1;
+    const int64_t items = (int64_t)(queueElementCount < r->cfg.livePaths ? queueElementCount : r->cfg.livePaths); /* :125-129 */
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int64_t qi = 0; qi < items; qi++) {
+        const uint32_t queueIndex = (uint32_t)qi;
         rng_t g; rng_seed(&g, &r->cam, queueIndex);                      /* :131 */
         uint32_t index = qUE4[queueIndex];                               /* :132 */
 
@@ -531,6 +555,7 @@ void orc_stage_material_ue4(orc_renderer* r) /* materialUE4.hlsl:118-192 */
 
         v3 lightDir = ld3(r, F_SHADOWRAY_DIRECTION, index);              /* :165 */
         int legitLight = vdot(lightDir, st.normal) > 0.0f;               /* :167 */
+        r->scratchKind[queueIndex] = (uint8_t)legitLight;
         if (legitLight) {                                                /* :178-190 */
             uint32_t lightIndex = ld1u(r, F_LIGHT_INDEX, index);
             float distance = ld1f(r, F_LIGHT_DISTANCE, index);
@@ -544,9 +569,10 @@ void orc_stage_material_ue4(orc_renderer* r) /* materialUE4.hlsl:118-192 */
             float fo = lightFalloff(distance, L->falloff);
             v3 dl = V(ph * e.x * L->emission[0] * lc * fo, ph * e.y * L->emission[1] * lc * fo, ph * e.z * L->emission[2] * lc * fo);
             st3(r, F_DIRECT_LIGHT, index, dl);                           /* :188 */
-            qSh[r->qc[QC_SHADOWRAY]++] = index;                          /* :189 */
         }
     }
+    for (uint32_t queueIndex = 0; queueIndex < (uint32_t)items; queueIndex++)
+        if (r->scratchKind[queueIndex]) qSh[r->qc[QC_SHADOWRAY]++] = qUE4[queueIndex]; /* :189 */
 }
 
 /* ------------------------------------------------------------------ stage 4: materialGlass.hlsl */
@@ -871,6 +897,8 @@ orc_renderer* orc_create(const orc_scene* scene, const orc_config* cfg)
     r->queue = (uint32_t*)calloc((size_t)r->cfg.poolPaths * 5, 4);
     r->fb = (float*)calloc((size_t)r->cfg.fbWidth * r->cfg.fbHeight * 4, 4);
     r->retired = (uint8_t*)calloc(r->cfg.poolPaths, 1);
+    r->scratchKind = (uint8_t*)calloc(cfg->poolPaths ? cfg->poolPaths : 1, 1);
+    r->scratchRad = (float*)calloc((size_t)(cfg->poolPaths ? cfg->poolPaths : 1) * 3, sizeof(float));
     r->activePaths = r->cfg.livePaths;
     if (!r->state || !r->queue || !r->fb || !r->retired) { orc_destroy(r); return NULL; }
     return r;
@@ -879,7 +907,7 @@ orc_renderer* orc_create(const orc_scene* scene, const orc_config* cfg)
 void orc_destroy(orc_renderer* r)
 {
     if (!r) return;
-    free(r->state); free(r->queue); free(r->fb); free(r->retired); free(r);
+    free(r->state); free(r->queue); free(r->fb); free(r->retired); free(r->scratchKind); free(r->scratchRad); free(r);
 }
 
 void orc_set_camera(orc_renderer* r, const orc_camera_buffer* cam)
