@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the counting replay that measures I and T")
     ap.add_argument("--no-stage-timing", action="store_true", help="do not record per-stage HIP events in the timed region")
-    ap.add_argument("--cpu-pool", type=int, default=1 << 16)
+    ap.add_argument("--cpu-pool", type=int, default=1 << 17)
     ap.add_argument("--cpu-iters", type=int, default=201)
     ap.add_argument("--cpu-prewarm", type=int, default=402)
     args = ap.parse_args()
