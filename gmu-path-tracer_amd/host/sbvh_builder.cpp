@@ -9,6 +9,9 @@
 //                        the reference ever takes)
 //   flatten              Source/BVHWrapper.cpp:56-95
 #include "sbvh_builder.hpp"
+#include <atomic>
+#include <future>
+#include <thread>
 
 #include <algorithm>
 #include <cfloat>
@@ -45,6 +48,35 @@ SbvhBuilder::SbvhBuilder(const float* vertices, uint32_t numVertices, const int3
 {
     for (uint32_t i = 0; i < numTriangles * 3u; i++)
         if (indices[i] < 0 || (uint32_t)indices[i] >= numVertices) throw std::invalid_argument("sbvh: vertex index out of range");
+}
+
+namespace {
+std::atomic<int> gForkedBuilds{ 0 };                 // subtree builds running on their own thread, over all builders of the process
+constexpr int kForkMinRefs = 4096;                   // both children must be at least this large to be worth a thread
+int forkLimit() { const unsigned hc = std::thread::hardware_concurrency(); return hc > 1 ? (int)(hc < 32 ? hc : 32) - 1 : 0; }
+}
+
+SbvhBuilder::SbvhBuilder(SbvhBuilder& parent, int numRef)
+    : mVerts(parent.mVerts), mIdx(parent.mIdx), mNumTris(parent.mNumTris), mP(parent.mP)
+{
+    mMinOverlap = parent.mMinOverlap;
+    mStack.assign(parent.mStack.end() - numRef, parent.mStack.end());
+    parent.mStack.resize(parent.mStack.size() - (size_t)numRef);
+    mRight.assign((size_t)std::max<int>(numRef, kBins) - 1, Aabb());
+}
+
+int32_t SbvhBuilder::absorb(const SbvhBuilder& sub, int32_t subRoot)
+{
+    const int32_t nodeOffset = (int32_t)mNodes.size(), refOffset = (int32_t)mRefTriangles.size();
+    for (SbvhNode n : sub.mNodes) {
+        if (n.child[0] < 0) { n.lo += refOffset; n.hi += refOffset; }
+        else { n.child[0] += nodeOffset; n.child[1] += nodeOffset; }
+        mNodes.push_back(n);
+    }
+    mRefTriangles.insert(mRefTriangles.end(), sub.mRefTriangles.begin(), sub.mRefTriangles.end());
+    mNumDuplicates += sub.mNumDuplicates;
+    if (sub.mDepth > mDepth) mDepth = sub.mDepth;
+    return subRoot + nodeOffset;
 }
 
 void SbvhBuilder::build()
@@ -104,9 +136,27 @@ int32_t SbvhBuilder::buildNode(const Spec& spec, int level)
     if (!left.numRef || !right.numRef) doObjectSplit(left, right, spec, object);
 
     mNumDuplicates += (uint32_t)(left.numRef + right.numRef - spec.numRef);
-    // the right child owns the top of the reference stack, so it is built first
-    const int32_t rightNode = buildNode(right, level + 1);
-    const int32_t leftNode = buildNode(left, level + 1);
+    // the right child owns the top of the reference stack, so it is built first -- or, when both children are large and a core is free,
+    // on another thread with its own copy of those references (same tree: a node only ever looks at its own references)
+    int32_t rightNode, leftNode;
+    bool forked = false;
+    if (left.numRef >= kForkMinRefs && right.numRef >= kForkMinRefs) {
+        const int limit = forkLimit();
+        if (gForkedBuilds.fetch_add(1) < limit) forked = true; else gForkedBuilds.fetch_sub(1);
+    }
+    if (forked) {
+        SbvhBuilder sub(*this, right.numRef);
+        std::future<int32_t> rightDone = std::async(std::launch::async, [&sub, right, level]() { return sub.buildNode(right, level + 1); });
+        try { leftNode = buildNode(left, level + 1); }
+        catch (...) { rightDone.wait(); gForkedBuilds.fetch_sub(1); throw; }
+        int32_t subRoot;
+        try { subRoot = rightDone.get(); } catch (...) { gForkedBuilds.fetch_sub(1); throw; }
+        gForkedBuilds.fetch_sub(1);
+        rightNode = absorb(sub, subRoot);
+    } else {
+        rightNode = buildNode(right, level + 1);
+        leftNode = buildNode(left, level + 1);
+    }
     SbvhNode n; n.bounds = spec.b; n.child[0] = leftNode; n.child[1] = rightNode; n.lo = n.hi = 0;
     mNodes.push_back(n);
     return (int32_t)mNodes.size() - 1;

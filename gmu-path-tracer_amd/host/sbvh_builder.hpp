@@ -55,6 +55,10 @@ private:
     struct ObjSplit { float sah; int dim; int numLeft; Aabb lb, rb; };
     struct SpaSplit { float sah; int dim; float pos; };
 
+    // sub-builder of one subtree: takes the top `numRef` references of the parent's stack (the parent keeps building the sibling on its
+    // own thread and absorbs the result afterwards).  The tree and every leaf's reference order are those of the sequential build.
+    SbvhBuilder(SbvhBuilder& parent, int numRef);
+    int32_t absorb(const SbvhBuilder& sub, int32_t subRoot);
     int32_t buildNode(const Spec& spec, int level);
     int32_t makeLeaf(const Spec& spec);
     ObjSplit findObjectSplit(const Spec& spec, float nodeSAH);
