@@ -85,6 +85,23 @@ def test_every_traversal_rung_gives_the_same_bits(pkg, device, soup_scene, monke
     hip.close(); sb.close(); orc.close()
 
 
+@pytest.mark.parametrize("knobs", [
+    {"GMUPT_RAYS_PER_WAVE": "64", "GMUPT_REFILL": "1", "GMUPT_TRI_THRESH": "1", "GMUPT_WAVES_PER_CU": "4"},
+    {"GMUPT_RAYS_PER_WAVE": "128", "GMUPT_REFILL": "64", "GMUPT_TRI_THRESH": "64", "GMUPT_WAVES_PER_CU": "16", "GMUPT_TOP_ORDER": "bfs"},
+], ids=["eager", "lazy"])
+def test_results_do_not_depend_on_scheduling_knobs(pkg, device, spheres_small_scene, monkeypatch, knobs):
+    # chunk size, refill threshold, triangle-burst threshold, grid size and the choice of LDS-resident nodes change how the ray casts
+    # are scheduled, never what they compute
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    W, H, P = 48, 27, 4096
+    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, spheres_small_scene, W, H, P)
+    for it in range(16):
+        PU.step_both(orc, hip, ocam, hcam)
+    _assert_same(orc, hip, P, P, 16)
+    hip.close(); sb.close(); orc.close()
+
+
 def test_deep_tree_uses_stack_overflow_path(pkg, device):
     # tree depth ~30: deeper than the LDS part of the traversal stacks (and than the reference's unchecked 16 entries, Q23)
     scene = pkg.scenes.build_scene(pkg.scenes.deep_chain_mesh())
