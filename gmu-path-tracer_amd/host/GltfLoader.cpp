@@ -190,12 +190,30 @@ void visitNode(const Gltf& g, int nodeIndex, const Mat4& parent, MeshData& out, 
 MeshData MeshData::loadGltf(const std::string& path)
 {
 	Gltf g;
-	g.doc = Json::parse(readFile(path, false));
+	std::string glbBin; bool haveGlbBin = false;
+	const bool glb = path.size() > 4 && path.compare(path.size() - 4, 4, ".glb") == 0;
+	if (glb) {
+		// binary container (glTF 2.0 specification, "GLB file format"): 12-byte header, then chunks (length, type, data): JSON first, BIN optional
+		const std::string file = readFile(path, true);
+		auto u32 = [&](size_t at) -> uint32_t { if (at + 4 > file.size()) throw std::runtime_error("GLB: truncated"); uint32_t v; std::memcpy(&v, file.data() + at, 4); return v; };
+		if (u32(0) != 0x46546C67u || u32(4) != 2u) throw std::runtime_error("GLB: bad magic or version");
+		size_t pos = 12; bool haveJson = false;
+		while (pos + 8 <= file.size()) {
+			const uint32_t len = u32(pos), type = u32(pos + 4);
+			if (pos + 8 + (size_t)len > file.size()) throw std::runtime_error("GLB: chunk exceeds the file");
+			if (type == 0x4E4F534Au && !haveJson) { g.doc = Json::parse(file.substr(pos + 8, len)); haveJson = true; }   // "JSON"
+			else if (type == 0x004E4942u && !haveGlbBin) { glbBin = file.substr(pos + 8, len); haveGlbBin = true; }      // "BIN\0"
+			pos += 8 + (size_t)len;
+		}
+		if (!haveJson) throw std::runtime_error("GLB: no JSON chunk");
+	}
+	else g.doc = Json::parse(readFile(path, false));
 	const std::string dir = path.find_last_of("/\\") == std::string::npos ? std::string() : path.substr(0, path.find_last_of("/\\") + 1);
 	for (size_t i = 0; i < g.doc["buffers"].size(); i++) {
 		const std::string& uri = g.doc["buffers"][i]["uri"].string();
 		const std::string tag = "base64,";
-		if (uri.compare(0, 5, "data:") == 0 && uri.find(tag) != std::string::npos) g.buffers.push_back(decodeBase64(uri.substr(uri.find(tag) + tag.size())));
+		if (uri.empty() && i == 0 && haveGlbBin) g.buffers.push_back(glbBin);                     // the BIN chunk is buffer 0 without a uri
+		else if (uri.compare(0, 5, "data:") == 0 && uri.find(tag) != std::string::npos) g.buffers.push_back(decodeBase64(uri.substr(uri.find(tag) + tag.size())));
 		else g.buffers.push_back(readFile(dir + uri, true));
 	}
 	MeshData out;

@@ -24,7 +24,7 @@ struct MeshData
 
 	// ".gmesh": little-endian dump written by gmu-path-tracer_amd/scenes.py (save_gmesh); throws std::runtime_error
 	static MeshData load(const std::string& path);
-	// glTF 2.0 (.gltf + external .bin or base64 buffers): triangulated, pre-transformed, smooth normals, flipped UVs -- the effect of the
+	// glTF 2.0 (.gltf + external .bin or base64 buffers, or a .glb container): triangulated, pre-transformed, smooth normals, flipped UVs -- the effect of the
 	// reference's assimp flags (Source/Scene.cpp:113-121); throws std::runtime_error
 	static MeshData loadGltf(const std::string& path);
 	// Config-2 Cornell box (34 triangles), identical to scenes.cornell_mesh()

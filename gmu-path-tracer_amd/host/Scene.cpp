@@ -65,7 +65,7 @@ void Scene::update(float dt)
 
 void Scene::loadScene(const std::string& path)
 {
-	const bool gltf = path.size() > 5 && path.compare(path.size() - 5, 5, ".gltf") == 0;
+	const bool gltf = (path.size() > 5 && path.compare(path.size() - 5, 5, ".gltf") == 0) || (path.size() > 4 && path.compare(path.size() - 4, 4, ".glb") == 0);
 	mScene = (path == "cornell") ? MeshData::cornell() : gltf ? MeshData::loadGltf(path) : MeshData::load(path);
 	if (mScene.materials.size() > MAX_LIGHTS) throw std::runtime_error("More than 128 materials (logic.hlsl:8)");
 }

@@ -45,7 +45,7 @@ int main(int argc, char** argv)
 			return 0;
 		}
 		if (buildOnly) { // host-only leg (BASELINE config 1): scene load + SBVH build + flatten, no GPU
-			const bool gltf = scene.size() > 5 && scene.compare(scene.size() - 5, 5, ".gltf") == 0;
+			const bool gltf = (scene.size() > 5 && scene.compare(scene.size() - 5, 5, ".gltf") == 0) || (scene.size() > 4 && scene.compare(scene.size() - 4, 4, ".glb") == 0);
 			MeshData mesh = (scene == "cornell") ? MeshData::cornell() : gltf ? MeshData::loadGltf(scene) : MeshData::load(scene);
 			// texture ingestion without the upload: layers, common size and checksum per texture type (Scene.cpp:209-244,268-285)
 			std::string texInfo = "[";

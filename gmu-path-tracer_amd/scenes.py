@@ -379,3 +379,32 @@ def save_gltf(mesh, path, node_transform=None, with_normals=True, texture_scale=
     out.update({"verts": np.concatenate(verts), "normals": np.concatenate(normals), "uv": np.concatenate(uvs), "vertex_material": np.concatenate(vmat),
                 "indices": np.concatenate(tris)})
     return out
+
+
+def gltf_to_glb(gltf_path, glb_path):
+    """Repacks a .gltf written by save_gltf (external .bin, external PNG images) as one binary .glb: the buffer becomes the BIN chunk,
+    the images become bufferViews of it.  The sibling .params file is copied."""
+    import json as _json, os as _os, struct as _struct, shutil as _shutil
+    folder = _os.path.dirname(gltf_path)
+    doc = _json.load(open(gltf_path))
+    blob = bytearray(open(_os.path.join(folder, doc["buffers"][0]["uri"]), "rb").read())
+    for img in doc.get("images", []):
+        data = open(_os.path.join(folder, img.pop("uri")), "rb").read()
+        while len(blob) % 4:
+            blob.append(0)
+        doc["bufferViews"].append({"buffer": 0, "byteOffset": len(blob), "byteLength": len(data)})
+        img["bufferView"] = len(doc["bufferViews"]) - 1; img["mimeType"] = "image/png"
+        blob.extend(data)
+    while len(blob) % 4:
+        blob.append(0)
+    doc["buffers"] = [{"byteLength": len(blob)}]
+    js = _json.dumps(doc).encode()
+    js += b" " * (-len(js) % 4)
+    total = 12 + 8 + len(js) + 8 + len(blob)
+    with open(glb_path, "wb") as f:
+        f.write(_struct.pack("<III", 0x46546C67, 2, total))
+        f.write(_struct.pack("<II", len(js), 0x4E4F534A)); f.write(js)
+        f.write(_struct.pack("<II", len(blob), 0x004E4942)); f.write(bytes(blob))
+    src = gltf_path.rsplit(".", 1)[0] + ".params"
+    if _os.path.exists(src):
+        _shutil.copyfile(src, glb_path.rsplit(".", 1)[0] + ".params")

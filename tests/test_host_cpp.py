@@ -78,6 +78,22 @@ def test_gltf_textures_are_decoded_indexed_and_resized(exe, pkg, tmp_path):
     assert [a.shape[1] for a in arrays] == [32, 16, 32]     # {16, 32} -> 32; all 16 -> 16; both normal maps doubled -> 32
 
 
+def test_glb_container_loads_like_the_gltf(exe, pkg, tmp_path):
+    # the same scene as .gltf (+ .bin + .png files) and as one binary .glb (BIN chunk, images as bufferViews): identical build and textures
+    path, written, arrays = _textured_gltf(pkg, tmp_path)
+    glb = str(tmp_path / "packed.glb")
+    pkg.scenes.gltf_to_glb(path, glb)
+    a = json.loads(subprocess.run([exe, "--build-only", "--scene", path], check=True, capture_output=True, text=True).stdout)
+    b = json.loads(subprocess.run([exe, "--build-only", "--scene", glb], check=True, capture_output=True, text=True).stdout)
+    for k in ("triangles", "vertices", "materials", "glass_materials", "nodes", "references", "sah", "bbox", "textures", "texture_indices"):
+        assert a[k] == b[k], k
+    assert b["textures"][0]["layers"] == 2
+    bad = open(glb, "rb").read()
+    (tmp_path / "bad.glb").write_bytes(b"glTX" + bad[4:])
+    r = subprocess.run([exe, "--build-only", "--scene", str(tmp_path / "bad.glb")], capture_output=True, text=True)
+    assert r.returncode != 0 and "GLB" in r.stderr
+
+
 def test_reference_params_files_parse(exe, tmp_path):
     # the values of the reference's own .params data files (tests/golden/reference_params.json), written back as CSV and parsed by
     # SceneParams::load (Source/Scene.cpp:34-55)
