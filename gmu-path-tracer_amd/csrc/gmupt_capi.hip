@@ -32,7 +32,6 @@ static_assert(offsetof(gmupt_material, metallic) == 16 && offsetof(gmupt_materia
 namespace gmupt {
 void launch_clear(const RenderParams& p, hipStream_t s);
 void launch_logic(const RenderParams& p, hipStream_t s);
-void launch_scan(const RenderParams& p, int clearFrame, hipStream_t s);
 void launch_material(const RenderParams& p, int clearFrame, hipStream_t s);
 void launch_extend(const RenderParams& p, uint32_t blocks, bool stats, int mode, hipStream_t s);
 void launch_shadow(const RenderParams& p, uint32_t blocks, bool stats, int mode, hipStream_t s);
@@ -306,7 +305,8 @@ extern "C" int gmupt_renderer_create(gmupt_device* dev, const gmupt_renderer_des
     if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.listNext, (size_t)P * 4, 0xFF);
     if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.sample, (size_t)P * 12, 0);
     if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.blockCounts, (size_t)p.nBlocks * 4 * kNumCounts, 0);
-    if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.blockOffsets, (size_t)p.nBlocks * 4 * kNumCounts, 0);
+    p.nGroups = (p.nBlocks + kScanGroup - 1) / kScanGroup; p.groupParity = 0;
+    if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.groupTotals, (size_t)2 * kNumCounts * p.nGroups * 4, 0);
     if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.queues, (size_t)P * 20, 0);
     if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.qc, 32, 0);
     if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.stats, sizeof(DevStats), 0);
@@ -524,14 +524,14 @@ static int run_iteration(gmupt_renderer* r, bool doShade, bool doExtend, bool do
         if (!extOnly) HIP_TRY(hipEventRecord(ev->e[0], r->stream));
     }
     if (doShade) {
+        r->p.groupParity ^= 1u;    // p is a reference to r->p: the launches of this iteration see the flipped half of the group totals
         if (clearFrame) launch_clear(p, r->stream); else launch_logic(p, r->stream);
         if (ev && !extOnly) HIP_TRY(hipEventRecord(ev->e[1], r->stream));
-        launch_scan(p, clearFrame, r->stream);
-        if (ev && !extOnly) HIP_TRY(hipEventRecord(ev->e[2], r->stream));
+        if (ev && !extOnly) HIP_TRY(hipEventRecord(ev->e[2], r->stream)); // (no scan launch any more: k_material computes its block offsets itself)
         launch_material(p, clearFrame, r->stream);
         if (ev) HIP_TRY(hipEventRecord(ev->e[3], r->stream));
     }
-    if (!doShade) HIP_TRY(hipMemsetAsync(p.travCounters, 0, 16, r->stream)); // k_scan zeroes the ray-cast work counters in a full iteration
+    if (!doShade) HIP_TRY(hipMemsetAsync(p.travCounters, 0, 16, r->stream)); // k_material (block 0) zeroes the ray-cast work counters in a full iteration
     if (doExtend && doShadow && traversal_is_fused(r->travMode)) {
         // one launch for both ray casts; its time is reported as the extension stage, the shadow stage as zero
         launch_cast(p, stats, r->travMode, r->stream);

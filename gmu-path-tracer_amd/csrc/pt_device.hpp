@@ -33,6 +33,7 @@ static_assert(F_COUNT == 50, "50 words per path");
 // per-slot class written by the logic kernel, consumed by the material kernel
 enum SlotClass : uint8_t { CLS_UE4 = 0, CLS_GLASS = 1, CLS_ENDED = 2, CLS_RETIRED = 3, CLS_NONE = 4, CLS_MASK = 0x0F, CLS_SHADOW_BIT = 0x10 };
 constexpr int kNumCounts = 4; // per-block counts: UE4, glass, ended, shadow-ray pushers
+constexpr uint32_t kScanGroup = 64; // blocks per group of the two-level rank computation
 
 // queue counters, same indices as the reference (structs.h:62-68); [7] is this build's live extension-queue length
 enum Counter : uint32_t { QC_NEWPATH = 0, QC_LASTPATHCNT = 1, QC_MATUE4 = 2, QC_MATGLASS = 3, QC_EXT_UE4_OFFSET = 4, QC_EXT_GLASS_OFFSET = 5, QC_SHADOWRAY = 6, QC_EXT_COUNT = 7 };
@@ -114,8 +115,10 @@ struct RenderParams {
     uint32_t* listHead;    // fbW * fbH
     float* sample;         // 3 * P: tonemapped sample of an ended path
     uint32_t* blockCounts; // kNumCounts * nBlocks
-    uint32_t* blockOffsets;// kNumCounts * nBlocks
     uint32_t nBlocks;
+    uint32_t* groupTotals; // 2 * kNumCounts * nGroups: class counts summed over groups of kScanGroup blocks, double-buffered by iteration parity
+    uint32_t nGroups;
+    uint32_t groupParity;  // which half the current iteration uses
     uint32_t* queues;      // 5 * P
     uint32_t* qc;          // 8
     DevStats* stats;
@@ -126,7 +129,7 @@ struct RenderParams {
     int* ovfStack;         // global overflow of the traversal stacks
     uint32_t ovfStride;    // threads of the traversal grid
     uint32_t raysPerWave;  // queue entries owned by one wave of the persistent ray-cast kernels
-    uint32_t* travCounters; // [0] extension, [1] shadow: next unassigned queue entry (zeroed by k_scan every iteration)
+    uint32_t* travCounters; // [0] extension, [1] shadow: next unassigned queue entry (zeroed by k_material every iteration)
     uint32_t travGridBlocks; // persistent ray-cast grid
     uint32_t extendPrune;  // 1: the extension ray skips boxes it enters beyond its current closest hit (see pt_traverse.hip)
     uint32_t shadowPrune;  // 1: the shadow ray skips boxes it enters beyond the light (cannot change its boolean result)

@@ -7,8 +7,10 @@
 //                Writes a 1-byte class per slot and per-block class counts instead of pushing to queues
 //                with per-warp atomics (the reference's NvBallot + InterlockedAdd idiom, logic.hlsl:36-44,
 //                263-285): queue positions are then RANKS, independent of scheduling order.
-//   k_scan       exclusive scan of the block counts (one workgroup) -> queue offsets + the seven counters.
-//   k_material   rank of every slot inside its class by wave64 ballot + mbcnt + block offset, then, fused by
+//                The block counts are also summed per group of 64 blocks (integer atomics, order-free).
+//   k_material   first its own queue offsets -- totals of the earlier groups + counts of the earlier blocks of its group: the result
+//                of an exclusive scan without a scan launch; block 0 hands the seven counters over -- then the rank of every slot
+//                inside its class by wave64 ballot + mbcnt + block offset, then, fused by
 //                class: framebuffer accumulation (logic.hlsl:49-73) + newPath.hlsl:14-61, materialUE4.hlsl:118-192,
 //                materialGlass.hlsl:48-85.  The RNG of those stages is seeded by the queue index
 //                (newPath.hlsl:27, materialUE4.hlsl:131, materialGlass.hlsl:61), so ranks must be the
@@ -99,6 +101,8 @@ __device__ __forceinline__ void publish_block_counts(const RenderParams& p, int 
         uint32_t s = 0;
         for (int w = 0; w < kBlock / 64; w++) s += s_cnt[threadIdx.x][w];
         p.blockCounts[threadIdx.x * p.nBlocks + blockIdx.x] = s;
+        // second level: totals per group of kScanGroup blocks (integer sums: the order of the atomics does not matter)
+        if (s) atomicAdd(&p.groupTotals[((size_t)p.groupParity * kNumCounts + threadIdx.x) * p.nGroups + blockIdx.x / kScanGroup], s);
     }
 }
 
@@ -237,64 +241,6 @@ __global__ __launch_bounds__(kBlock) void k_logic(RenderParams p)
     publish_block_counts(p, c);
 }
 
-// ------------------------------------------------------------------------------------------------ k_scan
-// One workgroup.  Exclusive scan of the per-block class counts, then the counter hand-over the reference does in
-// newPath.hlsl:55-60 (extension-queue offsets, shadow counter reset).
-__global__ __launch_bounds__(1024) void k_scan(RenderParams p, int clearFrame)
-{
-    __shared__ uint32_t s_wave[kNumCounts][16];
-    __shared__ uint32_t s_total[kNumCounts];
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const uint32_t chunk = (p.nBlocks + 1023u) / 1024u;
-    const uint32_t lo = t * chunk, hi = (lo + chunk < p.nBlocks) ? lo + chunk : p.nBlocks;
-    uint32_t sum[kNumCounts], incl[kNumCounts];
-#pragma unroll
-    for (int k = 0; k < kNumCounts; k++) {
-        uint32_t s = 0;
-        for (uint32_t b = lo; b < hi; b++) s += p.blockCounts[k * p.nBlocks + b];
-        sum[k] = s;
-        // inclusive scan inside the wave64 by DPP-free shuffles, then across the 16 waves through LDS
-        uint32_t v = s;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t n = __shfl_up(v, off); if (lane >= (uint32_t)off) v += n; }
-        incl[k] = v;
-        if (lane == 63) s_wave[k][wave] = v;
-    }
-    __syncthreads();
-    if (t < kNumCounts) {
-        uint32_t run = 0;
-        for (int w = 0; w < 16; w++) { const uint32_t c = s_wave[t][w]; s_wave[t][w] = run; run += c; }
-        s_total[t] = run;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kNumCounts; k++) {
-        uint32_t run = s_wave[k][wave] + incl[k] - sum[k]; // exclusive prefix of this thread's chunk
-        for (uint32_t b = lo; b < hi; b++) { const uint32_t cnt = p.blockCounts[k * p.nBlocks + b]; p.blockOffsets[k * p.nBlocks + b] = run; run += cnt; }
-    }
-    if (t == 0) {
-        const uint32_t nUE4 = s_total[CLS_UE4], nGlass = s_total[CLS_GLASS], nEnded = s_total[CLS_ENDED];
-        const uint32_t qc0 = clearFrame ? p.P : nEnded;            // logic.hlsl:178 stores PATHCOUNT on a clear
-        const uint32_t nNew = qc0 < p.L ? qc0 : p.L;               // newPath.hlsl:21-25 reaches at most the live slots
-        const uint32_t lastPath = p.qc[QC_LASTPATHCNT];
-        p.qc[QC_NEWPATH] = qc0;
-        p.qc[QC_MATUE4] = nUE4;
-        p.qc[QC_MATGLASS] = nGlass;
-        p.qc[QC_EXT_UE4_OFFSET] = qc0;                              // newPath.hlsl:57
-        p.qc[QC_EXT_GLASS_OFFSET] = qc0 + nUE4;                     // newPath.hlsl:58
-        p.qc[QC_SHADOWRAY] = s_total[3];                           // newPath.hlsl:59 resets it, materialUE4.hlsl:173 counts it up to this total
-        p.qc[QC_EXT_COUNT] = nNew + nUE4 + nGlass;
-        p.travCounters[0] = 0; p.travCounters[1] = 0;
-        uint32_t gen = nNew;
-        if (p.budget) { uint32_t remaining = p.budget > lastPath ? p.budget - lastPath : 0u; if (gen > remaining) gen = remaining; }
-        DevStats* st = p.stats;
-        if (clearFrame) st->activePaths = p.L;
-        st->activePaths -= (nNew - gen);
-        st->pathsGenerated += gen;
-        if (!clearFrame) { st->pathsCompleted += nEnded; st->segments += (unsigned long long)nEnded + nUE4 + nGlass; }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ material stages
 struct Ue4State { f3 rayDir; f3 baseColor; float metallic, roughness; f3 normal; };
 
@@ -365,7 +311,7 @@ __device__ __forceinline__ f3 ue4Evaluate(const Ue4State& st, f3 direction) // m
                (st.baseColor.z / kPi) * om + (D * F.z * G) / den);           // :114
 }
 
-__device__ __forceinline__ void stage_ue4(const RenderParams& p, uint32_t queueIndex, uint32_t index, uint32_t shadowRank) // materialUE4.hlsl:118-192
+__device__ __forceinline__ void stage_ue4(const RenderParams& p, uint32_t queueIndex, uint32_t index, uint32_t shadowRank, uint32_t extOffset) // materialUE4.hlsl:118-192
 {
     Rng g; g.seed(queueIndex, p.cam.randomSeed[0], p.cam.randomSeed[1]);   // :131
     Ue4State st;
@@ -387,7 +333,7 @@ __device__ __forceinline__ void stage_ue4(const RenderParams& p, uint32_t queueI
     const f3 surfacePoint = ld3(p, F_SP_X, index);                           // :157
     st3(p, F_RAY_OX, index, surfacePoint + bsdfDir * kEpsilonOffset);        // :158,160
     st3(p, F_RAY_DX, index, bsdfDir);                                        // :161
-    p.queues[(size_t)Q_EXT_RAY * p.P + p.qc[QC_EXT_UE4_OFFSET] + queueIndex] = index; // :162
+    p.queues[(size_t)Q_EXT_RAY * p.P + extOffset + queueIndex] = index;       // :162 (extOffset = QC[4])
 
     const f3 lightDir = ld3(p, F_SH_DX, index);                              // :165
     if (dot3(lightDir, st.normal) > 0.0f) {                                  // :167,178
@@ -407,7 +353,7 @@ __device__ __forceinline__ void stage_ue4(const RenderParams& p, uint32_t queueI
     }
 }
 
-__device__ __forceinline__ void stage_glass(const RenderParams& p, uint32_t queueIndex, uint32_t index) // materialGlass.hlsl:23-85
+__device__ __forceinline__ void stage_glass(const RenderParams& p, uint32_t queueIndex, uint32_t index, uint32_t extOffset) // materialGlass.hlsl:23-85
 {
     Rng g; g.seed(queueIndex, p.cam.randomSeed[0], p.cam.randomSeed[1]);   // :61
     const f3 rayDir = ld3(p, F_RAY_DX, index);
@@ -437,7 +383,7 @@ __device__ __forceinline__ void stage_glass(const RenderParams& p, uint32_t queu
     const f3 surfacePoint = ld3(p, F_SP_X, index);
     st3(p, F_RAY_OX, index, surfacePoint + bsdfDir * kEpsilonOffset);        // :79,81
     st3(p, F_RAY_DX, index, bsdfDir);                                        // :82
-    p.queues[(size_t)Q_EXT_RAY * p.P + p.qc[QC_EXT_GLASS_OFFSET] + queueIndex] = index; // :83
+    p.queues[(size_t)Q_EXT_RAY * p.P + extOffset + queueIndex] = index;       // :83 (extOffset = QC[5])
 }
 
 // running-mean update of one pixel for all paths that ended on it this iteration, in ascending slot order
@@ -505,6 +451,7 @@ __device__ __forceinline__ void stage_new_path(const RenderParams& p, uint32_t q
 __global__ __launch_bounds__(kBlock) void k_material(RenderParams p, int clearFrame)
 {
     __shared__ uint32_t s_cnt[kNumCounts][kBlock / 64];
+    __shared__ uint32_t s_pre[kNumCounts], s_tot[kNumCounts];
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t wave = threadIdx.x >> 6;
     const int cfull = (i < p.L) ? (int)p.cls[i] : (int)CLS_NONE;
@@ -512,11 +459,62 @@ __global__ __launch_bounds__(kBlock) void k_material(RenderParams p, int clearFr
     const bool shadow = cfull == (CLS_UE4 | CLS_SHADOW_BIT);
     const unsigned long long b0 = __ballot(c == CLS_UE4), b1 = __ballot(c == CLS_GLASS), b2 = __ballot(c == CLS_ENDED), b3 = __ballot(shadow);
     if ((threadIdx.x & 63) == 0) { s_cnt[0][wave] = __popcll(b0); s_cnt[1][wave] = __popcll(b1); s_cnt[2][wave] = __popcll(b2); s_cnt[3][wave] = __popcll(b3); }
+    if (threadIdx.x < kNumCounts) { s_pre[threadIdx.x] = 0; s_tot[threadIdx.x] = 0; }
     __syncthreads();
+
+    // ---- queue offsets of this block without a separate scan launch: (class counts of all earlier groups) + (of the earlier blocks of
+    // this group), and the totals over all groups (the queue counters of the reference).  Every block reads at most nGroups + 63 values
+    // per class; the sums are exact integers, so the ranks are those of a sequential scan.
+    {
+        const uint32_t* gt = p.groupTotals + (size_t)p.groupParity * kNumCounts * p.nGroups;
+        const uint32_t myGroup = blockIdx.x / kScanGroup, groupStart = myGroup * kScanGroup;
+        uint32_t pre[kNumCounts] = { 0, 0, 0, 0 }, tot[kNumCounts] = { 0, 0, 0, 0 };
+        for (uint32_t g = threadIdx.x; g < p.nGroups; g += kBlock)
+#pragma unroll
+            for (int k = 0; k < kNumCounts; k++) { const uint32_t v = gt[(size_t)k * p.nGroups + g]; tot[k] += v; if (g < myGroup) pre[k] += v; }
+        if (threadIdx.x < kScanGroup && groupStart + threadIdx.x < blockIdx.x)
+#pragma unroll
+            for (int k = 0; k < kNumCounts; k++) pre[k] += p.blockCounts[(size_t)k * p.nBlocks + groupStart + threadIdx.x];
+#pragma unroll
+        for (int k = 0; k < kNumCounts; k++) {
+            uint32_t a = pre[k], t = tot[k];
+            for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); t += __shfl_down(t, off); }
+            if ((threadIdx.x & 63) == 0) { if (a) atomicAdd(&s_pre[k], a); if (t) atomicAdd(&s_tot[k], t); }
+        }
+        __syncthreads();
+    }
+    const uint32_t nUE4 = s_tot[CLS_UE4], nGlass = s_tot[CLS_GLASS], nEnded = s_tot[CLS_ENDED], nShadow = s_tot[3];
+    const uint32_t qc0 = clearFrame ? p.P : nEnded;                 // logic.hlsl:178 stores PATHCOUNT on a clear
+    const uint32_t extUE4Offset = qc0, extGlassOffset = qc0 + nUE4; // newPath.hlsl:57-58
+
+    if (blockIdx.x == 0) {
+        // the other half of the group totals is the next iteration's: nobody reads or writes it during this launch
+        uint32_t* other = p.groupTotals + (size_t)(p.groupParity ^ 1u) * kNumCounts * p.nGroups;
+        for (uint32_t k = threadIdx.x; k < kNumCounts * p.nGroups; k += kBlock) other[k] = 0u;
+        if (threadIdx.x == 0) {
+            const uint32_t nNew = qc0 < p.L ? qc0 : p.L;           // newPath.hlsl:21-25 reaches at most the live slots
+            const uint32_t lastPath = p.qc[QC_LASTPATHCNT];
+            p.qc[QC_NEWPATH] = qc0;
+            p.qc[QC_MATUE4] = nUE4;
+            p.qc[QC_MATGLASS] = nGlass;
+            p.qc[QC_EXT_UE4_OFFSET] = extUE4Offset;
+            p.qc[QC_EXT_GLASS_OFFSET] = extGlassOffset;
+            p.qc[QC_SHADOWRAY] = nShadow;                          // newPath.hlsl:59 resets it, materialUE4.hlsl:173 counts it up to this total
+            p.qc[QC_EXT_COUNT] = nNew + nUE4 + nGlass;
+            p.travCounters[0] = 0; p.travCounters[1] = 0;
+            uint32_t gen = nNew;
+            if (p.budget) { uint32_t remaining = p.budget > lastPath ? p.budget - lastPath : 0u; if (gen > remaining) gen = remaining; }
+            DevStats* st = p.stats;
+            if (clearFrame) st->activePaths = p.L;
+            st->activePaths -= (nNew - gen);
+            st->pathsGenerated += gen;
+            if (!clearFrame) { st->pathsCompleted += nEnded; st->segments += (unsigned long long)nEnded + nUE4 + nGlass; }
+        }
+    }
     if (c > CLS_ENDED) return;
     // rank = slots of the same class with a smaller index: block offset + earlier waves + lower lanes
     const unsigned long long mine = (c == CLS_UE4) ? b0 : (c == CLS_GLASS) ? b1 : b2;
-    uint32_t rank = p.blockOffsets[c * p.nBlocks + blockIdx.x] + prefix_rank(mine);
+    uint32_t rank = s_pre[c] + prefix_rank(mine);
     for (uint32_t w = 0; w < wave; w++) rank += s_cnt[c][w];
 
     if (c == CLS_ENDED) stage_new_path(p, rank, i, clearFrame);
@@ -525,11 +523,11 @@ __global__ __launch_bounds__(kBlock) void k_material(RenderParams p, int clearFr
         if (c == CLS_UE4) {
             uint32_t srank = 0;
             if (shadow) {
-                srank = p.blockOffsets[3 * p.nBlocks + blockIdx.x] + prefix_rank(b3);
+                srank = s_pre[3] + prefix_rank(b3);
                 for (uint32_t w = 0; w < wave; w++) srank += s_cnt[3][w];
             }
-            stage_ue4(p, rank, i, srank);
-        } else stage_glass(p, rank, i);
+            stage_ue4(p, rank, i, srank, extUE4Offset);
+        } else stage_glass(p, rank, i, extGlassOffset);
     }
 }
 
@@ -557,7 +555,6 @@ static inline uint32_t slot_blocks(const RenderParams& p) { return p.nBlocks; }
 
 void launch_clear(const RenderParams& p, hipStream_t s) { hipLaunchKernelGGL(k_clear, dim3(slot_blocks(p)), dim3(kBlock), 0, s, p); }
 void launch_logic(const RenderParams& p, hipStream_t s) { hipLaunchKernelGGL(k_logic, dim3(slot_blocks(p)), dim3(kBlock), 0, s, p); }
-void launch_scan(const RenderParams& p, int clearFrame, hipStream_t s) { hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, p, clearFrame); }
 void launch_material(const RenderParams& p, int clearFrame, hipStream_t s) { hipLaunchKernelGGL(k_material, dim3(slot_blocks(p)), dim3(kBlock), 0, s, p, clearFrame); }
 void launch_detmath(int fn, const float* x, const float* y, float* out, uint32_t n, hipStream_t s)
 {

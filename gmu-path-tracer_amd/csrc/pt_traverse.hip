@@ -213,7 +213,7 @@ __device__ __forceinline__ void extend_body_d(const RenderParams& p, int* s_stac
     const uint32_t count = p.qc[QC_EXT_COUNT];
     const uint32_t* qExt = p.queues + (size_t)Q_EXT_RAY * p.P;
     // work distribution: a persistent grid; every wave takes chunks of p.raysPerWave queue entries from a device counter
-    // (one atomic per chunk; the counter is zeroed by k_scan) -- no wave waits for another one
+    // (one atomic per chunk; the counter is zeroed by k_material) -- no wave waits for another one
     uint32_t next = 0, end = 0;
     bool drained = false;
 
