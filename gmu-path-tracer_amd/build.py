@@ -10,9 +10,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libgmupt.so")
 
-DEVICE_SOURCES = ["csrc/pt_kernels.hip", "csrc/pt_traverse.hip", "csrc/pt_traverse_variants.hip", "csrc/gmupt_capi.hip"]
+DEVICE_SOURCES = ["csrc/pt_kernels.hip", "csrc/pt_traverse.hip", "csrc/pt_traverse_variants.hip", "csrc/gmupt_capi.hip"]   # pt_traverse_variants.hip is empty without -DGMUPT_VARIANTS
 HOST_SOURCES = ["host/sbvh_builder.cpp", "host/Camera.cpp", "host/TextureLoader.cpp"]
-HEADERS = ["csrc/pt_traverse_common.hpp", "csrc/pt_kernel_util.hpp", "host/MeshData.hpp", "host/BVHWrapper.hpp", "csrc/pt_device.hpp", "csrc/detmath.hpp", "host/sbvh_builder.hpp", "host/Camera.hpp", "host/TextureLoader.hpp", "host/png_reader.hpp", "host/Constants.hpp", "../include/gmupt.h"]
+HEADERS = ["csrc/pt_traverse_common.hpp", "csrc/pt_traverse_deferred.hpp", "csrc/pt_kernel_util.hpp", "host/MeshData.hpp", "host/BVHWrapper.hpp", "csrc/pt_device.hpp", "csrc/detmath.hpp", "host/sbvh_builder.hpp", "host/Camera.hpp", "host/TextureLoader.hpp", "host/png_reader.hpp", "host/Constants.hpp", "../include/gmupt.h"]
 
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
@@ -21,25 +21,49 @@ FLAGS = [
 ]
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+# Test-only builds of the same sources (tests/test_parity_gpu.py): the traversal ladder kept for A/B timing, and a build whose
+# two-level rank computation has one block per group (so that a small pool reaches the many-group paths of k_logic / k_material).
+TEST_BUILDS = {"variants": ["-DGMUPT_VARIANTS"], "scan1": ["-DGMUPT_SCAN_GROUP=1"]}
+EXPERIMENT_BUILDS = {"wide": ["-DGMUPT_WIDE_LINKS=1"]}   # A/B timing only (tools/), never loaded by tests
+
+
+def lib_path(name=None):
+    return LIB if not name else os.path.join(HERE, "libgmupt_%s.so" % name)
+
+
+def needs_build(name=None):
+    lib = lib_path(name)
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = DEVICE_SOURCES + HOST_SOURCES + HEADERS + ["build.py"]
     return any(os.path.getmtime(os.path.join(HERE, d)) > t for d in deps if os.path.exists(os.path.join(HERE, d)))
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return LIB
+def build(force=False, verbose=False, name=None):
+    """Builds libgmupt.so (name=None) or one of TEST_BUILDS (libgmupt_<name>.so); returns the path."""
+    lib = lib_path(name)
+    if not force and not needs_build(name):
+        return lib
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = os.environ.get("GMUPT_EXTRA_FLAGS", "").split()
-    cmd = [hipcc] + FLAGS + extra + ["-x", "hip"] + [os.path.join(HERE, s) for s in DEVICE_SOURCES + HOST_SOURCES] + ["-o", LIB]
+    extra = os.environ.get("GMUPT_EXTRA_FLAGS", "").split() + ({**TEST_BUILDS, **EXPERIMENT_BUILDS}[name] if name else [])
+    cmd = [hipcc] + FLAGS + extra + ["-x", "hip"] + [os.path.join(HERE, s) for s in DEVICE_SOURCES + HOST_SOURCES] + ["-o", lib]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=HERE)
-    return LIB
+    return lib
+
+
+def build_all(force=False, verbose=False):
+    """The shipped library and the test builds, compiled concurrently."""
+    from concurrent.futures import ThreadPoolExecutor
+    names = [None] + sorted(TEST_BUILDS)
+    with ThreadPoolExecutor(len(names)) as ex:
+        return list(ex.map(lambda n: build(force=force, verbose=verbose, name=n), names))
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--all" in sys.argv:
+        print("\n".join(build_all(force="--force" in sys.argv, verbose=True)))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

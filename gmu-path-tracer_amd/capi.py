@@ -47,7 +47,7 @@ class RendererDesc(C.Structure):
                 ("path_budget", C.c_uint32), ("max_depth", C.c_uint32), ("collect_stats", C.c_uint32)]
 
 
-STAT_STACK_OVERFLOW, STAT_FUSED_CAST = 1, 2
+STAT_STACK_OVERFLOW, STAT_FUSED_CAST, STAT_CAST_FETCH, STAT_STACK_SPILL = 1, 2, 4, 8
 
 
 class Stats(C.Structure):
@@ -60,7 +60,8 @@ class Stats(C.Structure):
                 ("ext_wave_inner", C.c_uint64), ("ext_wave_tris", C.c_uint64), ("sh_wave_inner", C.c_uint64), ("sh_wave_tris", C.c_uint64), ("ext_depth_hist", C.c_uint64 * 32),
                 ("lane_census", C.c_uint64 * 4), ("cast_waves", C.c_uint64), ("cast_wave_ticks", C.c_uint64), ("cast_wave_ticks_max", C.c_uint64),
                 ("cast_drain_ticks", C.c_uint64), ("cast_drain_iters", C.c_uint64), ("cast_drain_busy_lanes", C.c_uint64),
-                ("cast_wave_end_hist", C.c_uint64 * 32), ("ray_inner_hist", C.c_uint64 * 32)]
+                ("cast_wave_end_hist", C.c_uint64 * 32), ("ray_inner_hist", C.c_uint64 * 32),
+                ("ext_top_inner", C.c_uint64), ("sh_top_inner", C.c_uint64)]
 
     def as_dict(self):
         return {n: (list(getattr(self, n)) if hasattr(getattr(self, n), "__len__") else getattr(self, n)) for n, _ in self._fields_}
@@ -134,6 +135,18 @@ SYMBOLS = {
 }
 
 _lib = None
+_libs = {}
+
+
+def _load(path):
+    if path not in _libs:
+        handle = C.CDLL(path)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _libs[path] = handle
+    return _libs[path]
 
 
 def lib():
@@ -143,13 +156,30 @@ def lib():
         path = os.environ.get("GMUPT_LIB") or _build.LIB   # GMUPT_LIB: A/B timing of differently configured builds
         if not os.environ.get("GMUPT_LIB") and (not os.path.exists(path) or (os.path.exists("/opt/rocm/bin/hipcc") and _build.needs_build())):
             path = _build.build()
-        handle = C.CDLL(path)
-        for name, (res, args) in SYMBOLS.items():
-            fn = getattr(handle, name)  # AttributeError if the library does not export a declared symbol
-            fn.restype = res
-            fn.argtypes = args
-        _lib = handle
+        _lib = _load(path)
     return _lib
+
+
+class use_build:
+    """Context manager: inside the block every call of this module goes to a test build of the same sources (build.TEST_BUILDS,
+    e.g. "variants" = the library with the whole traversal ladder).  Objects created inside must be closed inside."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        global _lib
+        path = _build.lib_path(self.name)
+        if not os.path.exists(path) or (os.path.exists("/opt/rocm/bin/hipcc") and _build.needs_build(self.name)):
+            path = _build.build(name=self.name)
+        self.saved = lib()
+        _lib = _load(path)
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.saved
+        return False
 
 
 def _check(rc):

@@ -33,10 +33,11 @@ namespace gmupt {
 void launch_clear(const RenderParams& p, hipStream_t s);
 void launch_logic(const RenderParams& p, hipStream_t s);
 void launch_material(const RenderParams& p, int clearFrame, hipStream_t s);
-void launch_extend(const RenderParams& p, uint32_t blocks, bool stats, int mode, hipStream_t s);
-void launch_shadow(const RenderParams& p, uint32_t blocks, bool stats, int mode, hipStream_t s);
-void launch_cast(const RenderParams& p, bool stats, int mode, hipStream_t s);
+uint32_t launch_extend(const RenderParams& p, uint32_t blocks, bool stats, int mode, hipStream_t s);   // the launch_* of the ray casts return GMUPT_STAT_* bits of what they launched
+uint32_t launch_shadow(const RenderParams& p, uint32_t blocks, bool stats, int mode, hipStream_t s);
+uint32_t launch_cast(const RenderParams& p, bool stats, int mode, hipStream_t s);                      // 0: not launched, run the two separate casts
 bool traversal_is_fused(int mode);
+bool traversal_mode_available(int mode);
 void launch_detmath(int fn, const float* x, const float* y, float* out, uint32_t n, hipStream_t s);
 uint32_t traversal_block_threads();
 uint32_t deferred_block_threads();
@@ -191,7 +192,7 @@ extern "C" void gmupt_buffer_destroy(gmupt_buffer* buf)
 extern "C" size_t gmupt_buffer_size(const gmupt_buffer* buf) { return buf ? buf->bytes : 0; }
 
 // ------------------------------------------------------------------------------------------------ renderer
-struct StageEvents { hipEvent_t e[6]; bool extOnly = false; };
+struct StageEvents { hipEvent_t e[5]; bool extOnly = false; };   // logic | material | ray cast (extension) | shadow
 
 struct gmupt_renderer {
     gmupt_device* dev = nullptr;
@@ -204,11 +205,12 @@ struct gmupt_renderer {
     // timing
     int timing = 0; // 0 off, 1 all stages, 2 only the extension ray cast (two events per iteration)
     std::vector<StageEvents> evPool; size_t evUsed = 0;
-    double msStage[5] = { 0, 0, 0, 0, 0 }; uint64_t timedIters = 0;
+    double msStage[4] = { 0, 0, 0, 0 }; uint64_t timedIters = 0;
     std::vector<void*> allocs;
     // packed traversal copy of the bound scene
     void* travNodes = nullptr; void* travTris = nullptr; void* travRecs = nullptr;
-    int travMode = 40; // GMUPT_TRAVERSAL (A/B timing): default "def0" deferred-leaf kernels with the top of the tree in LDS | "defN" variants | "ififN" interleaved | "whilewhile" | "static" | "top" | "coop" | "ref" reference-layout buffers
+    int travMode = 60; // GMUPT_TRAVERSAL: "cast0" (default) both ray casts in one launch | "def0" separate launches; the other rungs of the ladder exist in -DGMUPT_VARIANTS builds only
+    uint32_t castFlags = 0; // GMUPT_STAT_* bits of the ray-cast kernels launched since the last reset
 };
 
 static int dev_alloc(gmupt_renderer* r, void** ptr, size_t bytes, int fill)
@@ -274,6 +276,10 @@ extern "C" int gmupt_renderer_create(gmupt_device* dev, const gmupt_renderer_des
     if (!r) return fail(GMUPT_ERR_OUT_OF_MEMORY, "gmupt_renderer_create: out of host memory");
     r->dev = dev; r->desc = *desc;
     r->travMode = parse_traversal_mode(std::getenv("GMUPT_TRAVERSAL"));
+    if (!traversal_mode_available(r->travMode)) {
+        delete r;
+        return fail(GMUPT_ERR_UNSUPPORTED, "gmupt_renderer_create: GMUPT_TRAVERSAL=%s is not part of this build (cast0 and def0 are; the other rungs need -DGMUPT_VARIANTS)", std::getenv("GMUPT_TRAVERSAL"));
+    }
     if (r->desc.pool_paths == 0) r->desc.pool_paths = GMUPT_PATHCOUNT;
     if (r->desc.live_paths == 0 || r->desc.live_paths > r->desc.pool_paths) r->desc.live_paths = r->desc.pool_paths;
     const uint32_t P = r->desc.pool_paths, L = r->desc.live_paths;
@@ -492,8 +498,8 @@ static int resolve_timing(gmupt_renderer* r)
     if (r->evUsed == 0) return GMUPT_OK;
     HIP_TRY(hipStreamSynchronize(r->stream));
     for (size_t k = 0; k < r->evUsed; k++) {
-        for (int sidx = 0; sidx < 5; sidx++) {
-            if (r->evPool[k].extOnly && sidx != 3) continue;
+        for (int sidx = 0; sidx < 4; sidx++) {
+            if (r->evPool[k].extOnly && sidx != 2) continue;
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, r->evPool[k].e[sidx], r->evPool[k].e[sidx + 1]));
             r->msStage[sidx] += ms;
@@ -527,21 +533,23 @@ static int run_iteration(gmupt_renderer* r, bool doShade, bool doExtend, bool do
         r->p.groupParity ^= 1u;    // p is a reference to r->p: the launches of this iteration see the flipped half of the group totals
         if (clearFrame) launch_clear(p, r->stream); else launch_logic(p, r->stream);
         if (ev && !extOnly) HIP_TRY(hipEventRecord(ev->e[1], r->stream));
-        if (ev && !extOnly) HIP_TRY(hipEventRecord(ev->e[2], r->stream)); // (no scan launch any more: k_material computes its block offsets itself)
-        launch_material(p, clearFrame, r->stream);
-        if (ev) HIP_TRY(hipEventRecord(ev->e[3], r->stream));
+        launch_material(p, clearFrame, r->stream);  // computes its own queue offsets (no scan launch)
+        if (ev) HIP_TRY(hipEventRecord(ev->e[2], r->stream));
     }
     if (!doShade) HIP_TRY(hipMemsetAsync(p.travCounters, 0, 16, r->stream)); // k_material (block 0) zeroes the ray-cast work counters in a full iteration
     if (doExtend && doShadow && traversal_is_fused(r->travMode)) {
         // one launch for both ray casts; its time is reported as the extension stage, the shadow stage as zero
-        launch_cast(p, stats, r->travMode, r->stream);
-        if (ev) HIP_TRY(hipEventRecord(ev->e[4], r->stream));
-        if (ev && !extOnly) HIP_TRY(hipEventRecord(ev->e[5], r->stream));
-        HIP_TRY(hipGetLastError());
-        return GMUPT_OK;
+        const uint32_t launched = launch_cast(p, stats, r->travMode, r->stream);
+        if (launched) {
+            r->castFlags |= launched;
+            if (ev) HIP_TRY(hipEventRecord(ev->e[3], r->stream));
+            if (ev && !extOnly) HIP_TRY(hipEventRecord(ev->e[4], r->stream));
+            HIP_TRY(hipGetLastError());
+            return GMUPT_OK;
+        }
     }
-    if (doExtend) { launch_extend(p, r->travBlocks, stats, r->travMode, r->stream); if (ev) HIP_TRY(hipEventRecord(ev->e[4], r->stream)); }
-    if (doShadow) { launch_shadow(p, r->travBlocks, stats, r->travMode, r->stream); if (ev && !extOnly) HIP_TRY(hipEventRecord(ev->e[5], r->stream)); }
+    if (doExtend) { r->castFlags |= launch_extend(p, r->travBlocks, stats, r->travMode, r->stream); if (ev) HIP_TRY(hipEventRecord(ev->e[3], r->stream)); }
+    if (doShadow) { r->castFlags |= launch_shadow(p, r->travBlocks, stats, r->travMode, r->stream); if (ev && !extOnly) HIP_TRY(hipEventRecord(ev->e[4], r->stream)); }
     HIP_TRY(hipGetLastError());
     return GMUPT_OK;
 }
@@ -579,10 +587,20 @@ extern "C" int gmupt_resize(gmupt_renderer* r, uint32_t width, uint32_t height)
     if (!r || width == 0 || height == 0) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_resize: bad argument");
     HIP_TRY(hipSetDevice(r->dev->id));
     HIP_TRY(hipStreamSynchronize(r->stream));
-    HIP_TRY(hipFree(r->p.fb)); r->p.fb = nullptr;
-    HIP_TRY(hipFree(r->p.listHead)); r->p.listHead = nullptr;
+    // the new target first: a failed allocation leaves the renderer on its old, still valid target
+    float4* oldFb = r->p.fb; uint32_t* oldHead = r->p.listHead; const uint32_t oldW = r->p.fbW, oldH = r->p.fbH;
+    r->p.fb = nullptr; r->p.listHead = nullptr;
+    const int rc = alloc_framebuffer(r, width, height);
+    if (rc != GMUPT_OK) {
+        if (r->p.fb) (void)hipFree(r->p.fb);
+        if (r->p.listHead) (void)hipFree(r->p.listHead);
+        r->p.fb = oldFb; r->p.listHead = oldHead; r->p.fbW = oldW; r->p.fbH = oldH;
+        return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    (void)hipFree(oldFb); (void)hipFree(oldHead);
     r->desc.width = width; r->desc.height = height;
-    return alloc_framebuffer(r, width, height);
+    return GMUPT_OK;
 }
 
 extern "C" int gmupt_read_framebuffer(gmupt_renderer* r, float* rgba, size_t bytes)
@@ -636,17 +654,19 @@ extern "C" int gmupt_get_stats(gmupt_renderer* r, gmupt_stats* out)
     std::memset(out, 0, sizeof(*out));
     out->iterations = r->iterations;
     out->paths_generated = ds.pathsGenerated; out->paths_completed = ds.pathsCompleted; out->segments = ds.segments;
-    out->active_paths = ds.activePaths; out->flags = (ds.stackOverflow ? GMUPT_STAT_STACK_OVERFLOW : 0u) | (traversal_is_fused(r->travMode) ? GMUPT_STAT_FUSED_CAST : 0u);
+    out->active_paths = ds.activePaths; out->flags = (ds.stackOverflow ? GMUPT_STAT_STACK_OVERFLOW : 0u) | r->castFlags;
     out->ext_rays = ds.extRays; out->ext_inner = ds.extInner; out->ext_leaves = ds.extLeaves; out->ext_tris = ds.extTris;
     out->sh_rays = ds.shRays; out->sh_inner = ds.shInner; out->sh_leaves = ds.shLeaves; out->sh_tris = ds.shTris;
-    out->ms_logic = r->msStage[0]; out->ms_scan = r->msStage[1]; out->ms_material = r->msStage[2];
+    out->ms_logic = r->msStage[0]; out->ms_material = r->msStage[1];
+    out->ms_scan = 0.0;       // no scan launch: the queue ranks are computed inside k_logic (group totals) and k_material (block prefixes)
     out->ms_accumulate = 0.0; // accumulation is fused into the material kernel
-    out->ms_extend = r->msStage[3]; out->ms_shadow = r->msStage[4];
+    out->ms_extend = r->msStage[2]; out->ms_shadow = r->msStage[3];
     out->timed_iterations = r->timedIters;
     for (int k = 0; k < 32; k++) { out->ext_depth_hist[k] = ds.extDepthHist[k]; out->cast_wave_end_hist[k] = ds.castWaveEndHist[k]; out->ray_inner_hist[k] = ds.rayInnerHist[k]; }
     for (int k = 0; k < 4; k++) out->lane_census[k] = ds.laneCensus[k];
     out->cast_waves = ds.castWaves; out->cast_wave_ticks = ds.castWaveClocks; out->cast_wave_ticks_max = ds.castWaveClocksMax;
     out->cast_drain_ticks = ds.castDrainClocks; out->cast_drain_iters = ds.castDrainIters; out->cast_drain_busy_lanes = ds.castDrainBusyLanes;
+    out->ext_top_inner = ds.extTopInner; out->sh_top_inner = ds.shTopInner;
     out->ext_wave_inner = ds.extWaveInner; out->ext_wave_tris = ds.extWaveTris; out->sh_wave_inner = ds.shWaveInner; out->sh_wave_tris = ds.shWaveTris;
     return GMUPT_OK;
 }
@@ -665,7 +685,7 @@ extern "C" int gmupt_reset_stats(gmupt_renderer* r)
     HIP_TRY(hipMemcpyAsync(r->p.stats, &ds, sizeof(ds), hipMemcpyHostToDevice, r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
     for (double& m : r->msStage) m = 0.0;
-    r->timedIters = 0; r->iterations = 0;
+    r->timedIters = 0; r->iterations = 0; r->castFlags = 0;
     return GMUPT_OK;
 }
 

@@ -33,7 +33,10 @@ static_assert(F_COUNT == 50, "50 words per path");
 // per-slot class written by the logic kernel, consumed by the material kernel
 enum SlotClass : uint8_t { CLS_UE4 = 0, CLS_GLASS = 1, CLS_ENDED = 2, CLS_RETIRED = 3, CLS_NONE = 4, CLS_MASK = 0x0F, CLS_SHADOW_BIT = 0x10 };
 constexpr int kNumCounts = 4; // per-block counts: UE4, glass, ended, shadow-ray pushers
-constexpr uint32_t kScanGroup = 64; // blocks per group of the two-level rank computation
+#ifndef GMUPT_SCAN_GROUP
+#define GMUPT_SCAN_GROUP 64
+#endif
+constexpr uint32_t kScanGroup = GMUPT_SCAN_GROUP; // blocks per group of the two-level rank computation (a -D knob so that a test build can reach many groups with a small pool)
 
 // queue counters, same indices as the reference (structs.h:62-68); [7] is this build's live extension-queue length
 enum Counter : uint32_t { QC_NEWPATH = 0, QC_LASTPATHCNT = 1, QC_MATUE4 = 2, QC_MATGLASS = 3, QC_EXT_UE4_OFFSET = 4, QC_EXT_GLASS_OFFSET = 5, QC_SHADOWRAY = 6, QC_EXT_COUNT = 7 };
@@ -56,6 +59,7 @@ struct DevStats {
     unsigned long long castDrainClocks, castDrainIters, castDrainBusyLanes; // after the wave found both queues empty: ticks, loop iterations, lanes with a ray summed over them
     unsigned long long castWaveEndHist[32]; // wave lifetimes in 50-us buckets (all waves of the persistent grid start together)
     unsigned long long rayInnerHist[32];    // extension rays by inner nodes visited, 16 per bucket
+    unsigned long long extTopInner, shTopInner; // inner-node visits served by the LDS-resident top of the tree (no vector-memory request)
     uint32_t activePaths;
     uint32_t stackOverflow; // traversal needed more than the provisioned stack (results then differ from an unbounded stack)
 };

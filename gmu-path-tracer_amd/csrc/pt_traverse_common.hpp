@@ -97,6 +97,12 @@ __device__ __forceinline__ void flush_counts(DevStats* st, const TravCount& tc, 
     }
 }
 
+__device__ __forceinline__ void flush_sum(unsigned long long* dst, uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(dst, (unsigned long long)v);
+}
+
 __device__ __forceinline__ void flush_wave_iters(DevStats* st, uint32_t wIn, uint32_t wTr, bool ext)
 {
     uint32_t a = wIn, b = wTr;

@@ -12,7 +12,8 @@
 // are resolved by visit order, `t < distance` strict, :64-74), the Moeller-Trumbore operation order (:38-77), and the
 // shadow acceptance rule t in (1e-8, 1e8), |d t| < lightDistance (shadowRayCast.hlsl:16-47,88-91).
 // What is free: memory layout, loop structure, and -- for the any-hit shadow ray only -- the visit order.
-#include "pt_traverse_common.hpp"
+#ifdef GMUPT_VARIANTS   // the whole file: A/B rungs, not part of the shipped library
+#include "pt_traverse_deferred.hpp"
 
 namespace gmupt {
 
@@ -1320,10 +1321,417 @@ __global__ __launch_bounds__(kCoopBlock) void k_shadow_c(RenderParams p)
     if (STATS) { flush_counts(p.stats, tc, rays, false); flush_wave_iters(p.stats, wIn, wTr, false); }
 }
 
+// Both ray casts in one persistent launch AND in one loop: a lane carries either an extension ray or a shadow ray (`kind`), so the
+// lanes that run out of extension rays take shadow rays while their neighbours are still walking -- no wave waits for its longest
+// extension ray before it starts on the shadow queue.  The walk is identical for both kinds; only the hit rule of the triangle burst
+// and the finish differ, and those run divergent only in the few iterations in which a wave holds both kinds.
+// `phase` (wave-uniform): 0 extension queue, 1 shadow queue, 2 both exhausted.  The opt-in prunings are not offered here.
+template <bool STATS, bool OVF, bool TOP, int REPS, int BURST>
+__global__ __launch_bounds__(kDefBlock) void k_cast_m(RenderParams p)
+{
+    GMUPT_DEF_LDS(TOP)
+    shadow_counter_epilogue(p);
+    const uint32_t gtid = blockIdx.x * kDefBlock + threadIdx.x;
+    DefStack<OVF> stk; stk.lds = s_stack + threadIdx.x; stk.ovf = p.ovfStack + gtid; stk.ovfStride = p.ovfStride; stk.ptr = 1;
+    s_stack[threadIdx.x] = kDone;
+    int* fifo = s_fifo + threadIdx.x;
+    TravCount tcE = { 0, 0, 0 }, tcS = { 0, 0, 0 }; uint32_t raysE = 0, raysS = 0, wInE = 0, wTrE = 0, wInS = 0, wTrS = 0;
+    const TravScene& ts = p.trav;
+    const uint32_t countExt = p.qc[QC_EXT_COUNT], countSh = p.qc[QC_SHADOWRAY];  // extensionRayCast.hlsl:205, shadowRayCast.hlsl:151
+    const uint32_t* qExt = p.queues + (size_t)Q_EXT_RAY * p.P;
+    const uint32_t* qSh = p.queues + (size_t)Q_SHADOW_RAY * p.P;
+    uint32_t next = 0, end = 0;
+    int phase = 0;
+    const unsigned long long tStart = STATS ? wall_clock64() : 0ull;
+    uint32_t rayInner = 0, census0 = 0, census1 = 0, census2 = 0, census3 = 0;
+
+    bool haveRay = false;
+    int kind = 0;                 // 0: extension ray, 1: shadow ray
+    uint32_t index = 0;
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), invdir = mk3(0, 0, 0);
+    float distance = kFltMax;     // extension: closest hit so far; shadow: distance of the light
+    float hu = 0.0f, hv = 0.0f;
+    int hitRef = -1;              // extension: triangle record of the closest hit; shadow: >= 0 when occluded
+    int cur = kDone;
+    uint32_t qHead = 0, qCount = 0;
+    int ti = -1;
+
+    for (;;) {
+        const bool idle = (cur == kDone) && (qCount == 0) && (ti < 0);
+        const unsigned long long idleMask = __ballot(idle);
+        const int nIdle = __popcll(idleMask);
+        if (nIdle == 64 || (nIdle >= (int)p.tuneRefill && phase < 2)) { // wave-uniform
+            while (next >= end && phase < 2) { // next chunk of the current queue, or the first one of the next queue
+                uint32_t base = 0;
+                if ((threadIdx.x & 63) == 0) base = atomicAdd(&p.travCounters[phase], p.raysPerWave);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                const uint32_t count = phase == 0 ? countExt : countSh;
+                if (base < count) { next = base; end = (base + p.raysPerWave < count) ? base + p.raysPerWave : count; }
+                else { phase++; next = end = 0; }
+            }
+            if (idle) {
+                if (haveRay) {
+                    if (STATS && kind == 0) { atomicAdd(&p.stats->rayInnerHist[rayInner / 16u < 31u ? rayInner / 16u : 31u], 1ull); rayInner = 0; }
+                    if (kind == 0) {
+                        // finish the extension ray: extensionRayCast.hlsl:218-232
+                        finish_extension_ray(p, index, o, d, distance, hu, hv, hitRef);
+                    } else {
+                        stu(p, F_IN_SHADOW, index, hitRef >= 0 ? 1u : 0u);   // shadowRayCast.hlsl:167
+                    }
+                    haveRay = false;
+                }
+                const uint32_t my = next + prefix_rank(idleMask);
+                if (my < end) {
+                    if (phase == 0) { // wave-uniform
+                        index = qExt[my];                                    // extensionRayCast.hlsl:210
+                        if (index != kQueueHole) {
+                            haveRay = true; kind = 0;
+                            if (STATS) raysE++;
+                            o = ld3(p, F_RAY_OX, index); d = ld3(p, F_RAY_DX, index); // :213-214
+                            distance = kFltMax;
+                        }
+                    } else {
+                        index = qSh[my];                                     // shadowRayCast.hlsl:159
+                        haveRay = true; kind = 1;
+                        if (STATS) raysS++;
+                        o = ld3(p, F_SH_OX, index); d = ld3(p, F_SH_DX, index); // :162-163
+                        distance = ldf(p, F_LIGHT_DIST, index);              // :164
+                    }
+                    if (haveRay) {
+                        invdir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        hitRef = -1; hu = 0.0f; hv = 0.0f;
+                        stk.reset(); qHead = 0; qCount = 0; ti = -1;
+                        cur = (ray_box(ts.rootMin[0], ts.rootMin[1], ts.rootMin[2], ts.rootMax[0], ts.rootMax[1], ts.rootMax[2], o, invdir) > 0.0f) ? ts.rootDesc : kDone;
+                    }
+                }
+            }
+            if (nIdle == 64 && phase == 2) break; // nothing in flight and both queues are exhausted (wave-uniform)
+            next = (next + (uint32_t)nIdle < end) ? next + (uint32_t)nIdle : end;
+        }
+
+        if (STATS) { // lane census: where do the 64 lanes of a wave spend the loop iterations?
+            const bool pendingNow = (qCount > 0) || (ti >= 0);
+            census0 += __popcll(__ballot(cur == kDone && !pendingNow)); census1 += __popcll(__ballot(cur >= 0));
+            census2 += __popcll(__ballot(cur < 0 && cur != kDone)); census3 += __popcll(__ballot(cur == kDone && pendingNow));
+        }
+        // ---- walk: REPS inner steps per lane; a reached leaf is queued and the walk goes on with the popped node
+#pragma unroll
+        for (int rep = 0; rep < REPS; rep++) {
+            if (cur >= 0) {
+                if (STATS) { if (kind == 0) { tcE.inner++; rayInner++; } else tcS.inner++; if (prefix_rank(__ballot(1)) == 0) { if (phase == 0) wInE++; else wInS++; } }
+                cur = inner_step_d<OVF, TOP>(ts, s_top, cur, o, invdir, stk, p.stats);
+            }
+            if (cur < 0 && cur != kDone && qCount < (uint32_t)kFifo) {
+                if (STATS) { if (kind == 0) tcE.leaves++; else tcS.leaves++; }
+                fifo[((qHead + qCount) & (kFifo - 1)) * kDefBlock] = ~cur;
+                qCount++;
+                cur = stk.pop();
+            }
+        }
+
+        // ---- triangle burst when enough lanes have leaves pending, or when nobody can walk any further
+        const bool pending = (qCount > 0) || (ti >= 0);
+        const int nPending = __popcll(__ballot(pending));
+        const int nWalking = __popcll(__ballot(cur >= 0));
+        if (nPending >= (int)p.tuneTriThresh || (nWalking == 0 && nPending > 0)) { // wave-uniform
+#pragma unroll
+            for (int k = 0; k < BURST; k++) {
+                if (ti < 0 && qCount > 0) { ti = fifo[(qHead & (kFifo - 1)) * kDefBlock]; qHead++; qCount--; }
+                if (ti >= 0) {
+                    if (STATS) { if (kind == 0) tcE.tris++; else tcS.tris++; if (prefix_rank(__ballot(1)) == 0) { if (phase == 0) wTrE++; else wTrS++; } }
+                    float t = 0.0f, u = 0.0f, v = 0.0f; bool last;
+                    if (tri_test(ts.tris, ti, o, d, t, u, v, last)) {
+                        if (kind == 0) {
+                            if (t >= 0.0f && t < distance) { distance = t; hitRef = ti; hu = u; hv = v; } // extensionRayCast.hlsl:64-74
+                        } else {
+                            // shadowRayCast.hlsl:41-45,89: t in (1e-8, 1e8) and |d t| < lightDistance => occluded: the ray is decided
+                            if (t > kEpsilon && t < 1.0f / kEpsilon && length3(d * t) < distance) { hitRef = ti; last = true; qCount = 0; cur = kDone; }
+                        }
+                    }
+                    ti = last ? -1 : ti + 1;
+                }
+            }
+        }
+    }
+    if (STATS) { flush_counts(p.stats, tcE, raysE, true); flush_wave_iters(p.stats, wInE, wTrE, true);
+                 flush_counts(p.stats, tcS, raysS, false); flush_wave_iters(p.stats, wInS, wTrS, false);
+                 if ((threadIdx.x & 63) == 0) {
+                     const unsigned long long life = wall_clock64() - tStart;
+                     atomicAdd(&p.stats->castWaves, 1ull); atomicAdd(&p.stats->castWaveClocks, life); atomicMax(&p.stats->castWaveClocksMax, life);
+                     atomicAdd(&p.stats->castWaveEndHist[life / 5000ull < 31ull ? life / 5000ull : 31ull], 1ull);
+                     atomicAdd(&p.stats->laneCensus[0], (unsigned long long)census0); atomicAdd(&p.stats->laneCensus[1], (unsigned long long)census1);
+                     atomicAdd(&p.stats->laneCensus[2], (unsigned long long)census2); atomicAdd(&p.stats->laneCensus[3], (unsigned long long)census3);
+                 } }
+}
+
+// ------------------------------------------------------------------------------------------------ three-slot lane pipeline
+// Lane census of the kernels above (collect_stats): 29 % of the lanes have no ray (they wait for the next batched refill, whose
+// finish-and-fetch code and two dependent loads stall the whole wave), 14 % have finished walking and wait for their queued leaves.
+// Here a lane owns three ray slots: PREFETCHED (queue entry, origin, direction, reciprocal direction and root test are fetched and
+// computed ahead, in batches, two loop iterations before they are needed), ACTIVE (walking / testing) and RESULT (a finished ray whose
+// stores are issued later, in batches).  A lane that finishes a ray moves it to its result slot and starts its prefetched ray in the
+// same iteration with register moves only; nothing in the hot loop waits for a ray fetch.  Per-ray arithmetic and order: unchanged.
+constexpr int kFinishBatch = 24;    // issue the result stores when this many lanes hold a finished ray
+constexpr int kPrefetchBatch = 8;   // request new queue entries when this many lanes have an empty prefetch slot
+
+template <bool STATS, bool OVF, bool TOP, int REPS, int BURST>
+__global__ __launch_bounds__(kDefBlock) void k_extend_e(RenderParams p)
+{
+    __shared__ int s_stack[kDefStack * kDefBlock];
+    __shared__ int s_fifo[kFifo * kDefBlock];
+    __shared__ float4 s_top[TOP ? kTopTreeNodes * 4 : 4];
+    if (TOP) {
+        const float4* src = reinterpret_cast<const float4*>(p.trav.nodes);
+        for (uint32_t k = threadIdx.x; k < p.trav.topCount * 4u; k += kDefBlock) s_top[k] = src[k];
+        __syncthreads();
+    }
+    const uint32_t gtid = blockIdx.x * kDefBlock + threadIdx.x;
+    DefStack<OVF> stk; stk.lds = s_stack + threadIdx.x; stk.ovf = p.ovfStack + gtid; stk.ovfStride = p.ovfStride; stk.ptr = 1;
+    s_stack[threadIdx.x] = kDone;
+    int* fifo = s_fifo + threadIdx.x;
+    TravCount tc = { 0, 0, 0 }; uint32_t rays = 0, wIn = 0, wTr = 0;
+    const TravScene& ts = p.trav;
+    const uint32_t count = p.qc[QC_EXT_COUNT];
+    const uint32_t* qExt = p.queues + (size_t)Q_EXT_RAY * p.P;
+    uint32_t next = 0, end = 0;      // current chunk of the extension queue (wave-uniform)
+    bool drained = false;            // the device work counter is exhausted (wave-uniform)
+
+    // ACTIVE slot
+    bool haveRay = false;
+    uint32_t index = 0;
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), invdir = mk3(0, 0, 0);
+    float distance = kFltMax, hu = 0.0f, hv = 0.0f;
+    int hitRef = -1, cur = kDone;
+    uint32_t qHead = 0, qCount = 0;
+    int ti = -1;
+    // RESULT slot
+    bool resValid = false;
+    uint32_t rIndex = 0; f3 rO = mk3(0, 0, 0), rD = mk3(0, 0, 1); float rDist = kFltMax, rHu = 0.0f, rHv = 0.0f; int rHit = -1;
+    // PREFETCH slot: 0 empty, 1 queue entry requested, 2 ray requested, 3 ready
+    int pf = 0;
+    uint32_t pfIndex = 0; f3 pfO = mk3(0, 0, 0), pfD = mk3(0, 0, 1), pfInv = mk3(0, 0, 0); int pfCur = kDone;
+
+    for (;;) {
+        // (a) a finished ray moves to the result slot (register moves)
+        if (haveRay && cur == kDone && qCount == 0 && ti < 0 && !resValid) {
+            resValid = true; rIndex = index; rO = o; rD = d; rDist = distance; rHu = hu; rHv = hv; rHit = hitRef;
+            haveRay = false;
+        }
+        // (b) an empty active slot takes the prefetched ray (register moves)
+        if (!haveRay && pf == 3) {
+            haveRay = true; index = pfIndex; o = pfO; d = pfD; invdir = pfInv; cur = pfCur;
+            distance = kFltMax; hitRef = -1; hu = 0.0f; hv = 0.0f;
+            stk.reset(); qHead = 0; qCount = 0; ti = -1;
+            pf = 0;
+            if (STATS) rays++;
+        }
+        const unsigned long long busyMask = __ballot(haveRay);
+        // (c) finish rays in batches: extensionRayCast.hlsl:218-232
+        {
+            const int nRes = __popcll(__ballot(resValid));
+            const bool blocked = haveRay && cur == kDone && qCount == 0 && ti < 0;    // finished, but its result slot is still occupied
+            if (nRes >= kFinishBatch || __ballot(blocked) != 0ull || (busyMask == 0ull && nRes > 0)) { // wave-uniform
+                if (resValid) {
+                    float dist = rDist;
+                    finish_extension_ray(p, rIndex, rO, rD, dist, rHu, rHv, rHit);
+                    resValid = false;
+                }
+            }
+        }
+        // (d) prefetch pipeline, youngest stage last so that a slot advances one stage per iteration
+        if (pf == 2) { // ray data has arrived: reciprocal direction and root test, once per ray (extensionRayCast.hlsl:81,103-105)
+            pfInv = mk3(1.0f / pfD.x, 1.0f / pfD.y, 1.0f / pfD.z);
+            pfCur = (ray_box(ts.rootMin[0], ts.rootMin[1], ts.rootMin[2], ts.rootMax[0], ts.rootMax[1], ts.rootMax[2], pfO, pfInv) > 0.0f) ? ts.rootDesc : kDone;
+            pf = 3;
+        }
+        if (pf == 1) { // the queue entry has arrived: request the ray (:213-214), or drop a hole left by a retired slot
+            if (pfIndex == kQueueHole) pf = 0;
+            else { pfO = ld3(p, F_RAY_OX, pfIndex); pfD = ld3(p, F_RAY_DX, pfIndex); pf = 2; }
+        }
+        {
+            const unsigned long long needMask = __ballot(pf == 0);
+            const int nNeed = __popcll(needMask);
+            if (!drained && (nNeed >= kPrefetchBatch || (busyMask == 0ull && nNeed > 0))) { // wave-uniform
+                if (next >= end) {
+                    uint32_t base = 0;
+                    if ((threadIdx.x & 63) == 0) base = atomicAdd(&p.travCounters[0], p.raysPerWave);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    next = base; end = (base + p.raysPerWave < count) ? base + p.raysPerWave : count;
+                    if (base >= count) { drained = true; next = end = 0; }
+                }
+                if (pf == 0) {
+                    const uint32_t my = next + prefix_rank(needMask);
+                    if (my < end) { pfIndex = qExt[my]; pf = 1; }                 // :210
+                }
+                next = (next + (uint32_t)nNeed < end) ? next + (uint32_t)nNeed : end;
+            }
+        }
+        // (e) done when nothing is in flight anywhere in the wave and the queue is exhausted
+        if (drained && busyMask == 0ull && __ballot(resValid || pf != 0) == 0ull) break;
+
+        // (f) walk: REPS inner steps per lane; a reached leaf is queued and the walk goes on with the popped node
+#pragma unroll
+        for (int rep = 0; rep < REPS; rep++) {
+            if (cur >= 0) {
+                if (STATS) { tc.inner++; if (prefix_rank(__ballot(1)) == 0) wIn++; }
+                cur = inner_step_d<OVF, TOP>(ts, s_top, cur, o, invdir, stk, p.stats);
+            }
+            if (cur < 0 && cur != kDone && qCount < (uint32_t)kFifo) {
+                if (STATS) tc.leaves++;
+                fifo[((qHead + qCount) & (kFifo - 1)) * kDefBlock] = ~cur;
+                qCount++;
+                cur = stk.pop();
+            }
+        }
+        // (g) triangle burst when enough lanes have leaves pending, or when nobody can walk any further
+        const bool pending = (qCount > 0) || (ti >= 0);
+        const int nPending = __popcll(__ballot(pending));
+        const int nWalking = __popcll(__ballot(cur >= 0));
+        if (nPending >= (int)p.tuneTriThresh || (nWalking == 0 && nPending > 0)) { // wave-uniform
+#pragma unroll
+            for (int k = 0; k < BURST; k++) {
+                if (ti < 0 && qCount > 0) { ti = fifo[(qHead & (kFifo - 1)) * kDefBlock]; qHead++; qCount--; }
+                if (ti >= 0) {
+                    if (STATS) { tc.tris++; if (prefix_rank(__ballot(1)) == 0) wTr++; }
+                    float t = 0.0f, u = 0.0f, v = 0.0f; bool last;
+                    if (tri_test(ts.tris, ti, o, d, t, u, v, last)) {
+                        if (t >= 0.0f && t < distance) { distance = t; hitRef = ti; hu = u; hv = v; } // extensionRayCast.hlsl:64-74
+                    }
+                    ti = last ? -1 : ti + 1;
+                }
+            }
+        }
+    }
+    if (STATS) { flush_counts(p.stats, tc, rays, true); flush_wave_iters(p.stats, wIn, wTr, true); }
+}
+
+template <bool STATS, bool OVF, bool TOP, int REPS, int BURST>
+__global__ __launch_bounds__(kDefBlock) void k_shadow_e(RenderParams p)
+{
+    __shared__ int s_stack[kDefStack * kDefBlock];
+    __shared__ int s_fifo[kFifo * kDefBlock];
+    __shared__ float4 s_top[TOP ? kTopTreeNodes * 4 : 4];
+    if (TOP) {
+        const float4* src = reinterpret_cast<const float4*>(p.trav.nodes);
+        for (uint32_t k = threadIdx.x; k < p.trav.topCount * 4u; k += kDefBlock) s_top[k] = src[k];
+    }
+    const uint32_t gtid = blockIdx.x * kDefBlock + threadIdx.x;
+    const uint32_t count = p.qc[QC_SHADOWRAY];                               // shadowRayCast.hlsl:151
+    __syncthreads();
+    if (gtid == 0) {
+        // :144-148: QC[0..3] = (0, QC1 + QC0, 0, 0).  Nothing else in this kernel reads those words.
+        const uint32_t q0 = p.qc[QC_NEWPATH], q1 = p.qc[QC_LASTPATHCNT];
+        p.qc[QC_NEWPATH] = 0; p.qc[QC_LASTPATHCNT] = q0 + q1; p.qc[QC_MATUE4] = 0; p.qc[QC_MATGLASS] = 0;
+    }
+    DefStack<OVF> stk; stk.lds = s_stack + threadIdx.x; stk.ovf = p.ovfStack + gtid; stk.ovfStride = p.ovfStride; stk.ptr = 1;
+    s_stack[threadIdx.x] = kDone;
+    int* fifo = s_fifo + threadIdx.x;
+    TravCount tc = { 0, 0, 0 }; uint32_t rays = 0, wIn = 0, wTr = 0;
+    const TravScene& ts = p.trav;
+    const uint32_t* qSh = p.queues + (size_t)Q_SHADOW_RAY * p.P;
+    uint32_t next = 0, end = 0;
+    bool drained = false;
+
+    bool haveRay = false, occluded = false;
+    uint32_t index = 0;
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), invdir = mk3(0, 0, 0);
+    float lightDistance = 0.0f;
+    int cur = kDone;
+    uint32_t qHead = 0, qCount = 0;
+    int ti = -1;
+    bool resValid = false; uint32_t rIndex = 0; bool rOccluded = false;
+    int pf = 0;
+    uint32_t pfIndex = 0; f3 pfO = mk3(0, 0, 0), pfD = mk3(0, 0, 1), pfInv = mk3(0, 0, 0); float pfLight = 0.0f; int pfCur = kDone;
+
+    for (;;) {
+        if (haveRay && cur == kDone && qCount == 0 && ti < 0 && !resValid) { resValid = true; rIndex = index; rOccluded = occluded; haveRay = false; }
+        if (!haveRay && pf == 3) {
+            haveRay = true; index = pfIndex; o = pfO; d = pfD; invdir = pfInv; lightDistance = pfLight; cur = pfCur; occluded = false;
+            stk.reset(); qHead = 0; qCount = 0; ti = -1;
+            pf = 0;
+            if (STATS) rays++;
+        }
+        const unsigned long long busyMask = __ballot(haveRay);
+        {
+            const int nRes = __popcll(__ballot(resValid));
+            const bool blocked = haveRay && cur == kDone && qCount == 0 && ti < 0;
+            if (nRes >= kFinishBatch || __ballot(blocked) != 0ull || (busyMask == 0ull && nRes > 0)) {
+                if (resValid) { stu(p, F_IN_SHADOW, rIndex, rOccluded ? 1u : 0u); resValid = false; }   // :167
+            }
+        }
+        if (pf == 2) {
+            pfInv = mk3(1.0f / pfD.x, 1.0f / pfD.y, 1.0f / pfD.z);
+            pfCur = (ray_box(ts.rootMin[0], ts.rootMin[1], ts.rootMin[2], ts.rootMax[0], ts.rootMax[1], ts.rootMax[2], pfO, pfInv) > 0.0f) ? ts.rootDesc : kDone;
+            pf = 3;
+        }
+        if (pf == 1) { pfO = ld3(p, F_SH_OX, pfIndex); pfD = ld3(p, F_SH_DX, pfIndex); pfLight = ldf(p, F_LIGHT_DIST, pfIndex); pf = 2; } // :162-164
+        {
+            const unsigned long long needMask = __ballot(pf == 0);
+            const int nNeed = __popcll(needMask);
+            if (!drained && (nNeed >= kPrefetchBatch || (busyMask == 0ull && nNeed > 0))) {
+                if (next >= end) {
+                    uint32_t base = 0;
+                    if ((threadIdx.x & 63) == 0) base = atomicAdd(&p.travCounters[1], p.raysPerWave);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    next = base; end = (base + p.raysPerWave < count) ? base + p.raysPerWave : count;
+                    if (base >= count) { drained = true; next = end = 0; }
+                }
+                if (pf == 0) {
+                    const uint32_t my = next + prefix_rank(needMask);
+                    if (my < end) { pfIndex = qSh[my]; pf = 1; }                  // :159
+                }
+                next = (next + (uint32_t)nNeed < end) ? next + (uint32_t)nNeed : end;
+            }
+        }
+        if (drained && busyMask == 0ull && __ballot(resValid || pf != 0) == 0ull) break;
+
+#pragma unroll
+        for (int rep = 0; rep < REPS; rep++) {
+            if (cur >= 0) {
+                if (STATS) { tc.inner++; if (prefix_rank(__ballot(1)) == 0) wIn++; }
+                cur = inner_step_d<OVF, TOP>(ts, s_top, cur, o, invdir, stk, p.stats);
+            }
+            if (cur < 0 && cur != kDone && qCount < (uint32_t)kFifo) {
+                if (STATS) tc.leaves++;
+                fifo[((qHead + qCount) & (kFifo - 1)) * kDefBlock] = ~cur;
+                qCount++;
+                cur = stk.pop();
+            }
+        }
+        const bool pending = (qCount > 0) || (ti >= 0);
+        const int nPending = __popcll(__ballot(pending));
+        const int nWalking = __popcll(__ballot(cur >= 0));
+        if (nPending >= (int)p.tuneTriThresh || (nWalking == 0 && nPending > 0)) {
+#pragma unroll
+            for (int k = 0; k < BURST; k++) {
+                if (ti < 0 && qCount > 0) { ti = fifo[(qHead & (kFifo - 1)) * kDefBlock]; qHead++; qCount--; }
+                if (ti >= 0) {
+                    if (STATS) { tc.tris++; if (prefix_rank(__ballot(1)) == 0) wTr++; }
+                    float t = 0.0f, u = 0.0f, v = 0.0f; bool last;
+                    if (tri_test(ts.tris, ti, o, d, t, u, v, last)) {
+                        // shadowRayCast.hlsl:41-45,89: t in (1e-8, 1e8) and |d t| < lightDistance => occluded: the ray is decided
+                        if (t > kEpsilon && t < 1.0f / kEpsilon && length3(d * t) < lightDistance) { occluded = true; last = true; qCount = 0; cur = kDone; }
+                    }
+                    ti = last ? -1 : ti + 1;
+                }
+            }
+        }
+    }
+    if (STATS) { flush_counts(p.stats, tc, rays, false); flush_wave_iters(p.stats, wIn, wTr, false); }
+}
+
 // ------------------------------------------------------------------------------------------------ host launchers
 void launch_extend_variant(const RenderParams& p, uint32_t blocks, bool stats, int mode, hipStream_t s)
 {
-    if (mode == 30) {
+    if (mode >= 50) {   // pipeN: three ray slots per lane
+        const uint32_t pb = p.travGridBlocks;
+        const bool ovf = p.trav.maxDepth + 2 > (uint32_t)kDefStack;
+        switch (mode - 50) {
+        case 0: GMUPT_DEF_LAUNCH(k_extend_e, true, 4, 4); break;
+        case 1: GMUPT_DEF_LAUNCH(k_extend_e, true, 3, 4); break;
+        default: GMUPT_DEF_LAUNCH(k_extend_e, true, 2, 4); break;
+        }
+    } else if (mode == 30) {
         const uint32_t pb = (p.L + p.raysPerWave * (kTravBlock / 64) - 1) / (p.raysPerWave * (kTravBlock / 64));
         if (stats) hipLaunchKernelGGL((k_extend_t<true, 2, 20>), dim3(pb), dim3(kTravBlock), 0, s, p);
         else hipLaunchKernelGGL((k_extend_t<false, 2, 20>), dim3(pb), dim3(kTravBlock), 0, s, p);
@@ -1351,7 +1759,15 @@ void launch_extend_variant(const RenderParams& p, uint32_t blocks, bool stats, i
 }
 void launch_shadow_variant(const RenderParams& p, uint32_t blocks, bool stats, int mode, hipStream_t s)
 {
-    if (mode == 30) {
+    if (mode >= 50) {   // pipeN: three ray slots per lane
+        const uint32_t pb = p.travGridBlocks;
+        const bool ovf = p.trav.maxDepth + 2 > (uint32_t)kDefStack;
+        switch (mode - 50) {
+        case 0: GMUPT_DEF_LAUNCH(k_shadow_e, true, 4, 4); break;
+        case 1: GMUPT_DEF_LAUNCH(k_shadow_e, true, 3, 4); break;
+        default: GMUPT_DEF_LAUNCH(k_shadow_e, true, 2, 4); break;
+        }
+    } else if (mode == 30) {
         const uint32_t pb = (p.L + p.raysPerWave * (kTravBlock / 64) - 1) / (p.raysPerWave * (kTravBlock / 64));
         if (stats) hipLaunchKernelGGL((k_shadow_t<true, 2, 20>), dim3(pb), dim3(kTravBlock), 0, s, p);
         else hipLaunchKernelGGL((k_shadow_t<false, 2, 20>), dim3(pb), dim3(kTravBlock), 0, s, p);
@@ -1379,4 +1795,15 @@ void launch_shadow_variant(const RenderParams& p, uint32_t blocks, bool stats, i
 }
 uint32_t variant_overflow_entries() { return kMaxStack + 1 - kCoopStack; } // sized for the variant with the smallest LDS stack
 
+
+bool launch_cast_variant(const RenderParams& p, bool stats, int mode, hipStream_t s)
+{
+    (void)mode;
+    const uint32_t pb = p.travGridBlocks;
+    const bool ovf = p.trav.maxDepth + 2 > (uint32_t)kDefStack;
+    GMUPT_DEF_LAUNCH(k_cast_m, true, 4, 4);
+    return true;
+}
+
 } // namespace gmupt
+#endif // GMUPT_VARIANTS

@@ -153,19 +153,23 @@ int gmupt_get_counters(gmupt_renderer* r, uint32_t out[8]);
 int gmupt_synchronize(gmupt_renderer* r);
 
 #define GMUPT_STAT_STACK_OVERFLOW 1u /* a traversal stack exceeded 64 entries (results invalid; never seen on a builder-made tree) */
-#define GMUPT_STAT_FUSED_CAST 2u     /* both ray casts run as one launch: ms_extend is the time of that launch, ms_shadow is 0 */
+#define GMUPT_STAT_FUSED_CAST 2u     /* both ray casts ran as one launch: ms_extend is the time of that launch, ms_shadow is 0 */
+#define GMUPT_STAT_CAST_FETCH 4u     /* that launch was k_cast_f (the default kernel; it needs node / triangle arrays below 2 GiB each) */
+#define GMUPT_STAT_STACK_SPILL 8u    /* the tree is deeper than the LDS part of the traversal stacks: the instantiation with the bounds-checked
+                                        global spill ran (results are the same; GMUPT_STAT_STACK_OVERFLOW is the error flag) */
 typedef struct {
     uint64_t iterations;
     uint64_t paths_generated;    /* new paths started (device counter) */
     uint64_t paths_completed;    /* paths accumulated into the framebuffer */
     uint64_t segments;           /* live-slot iterations (the reference overlay's "MP/s" unit, GUI.cpp:48) */
     uint32_t active_paths;       /* slots not retired by path_budget */
-    uint32_t flags;              /* GMUPT_STAT_* bits */
+    uint32_t flags;              /* GMUPT_STAT_* bits; the ray-cast bits describe the launches since the last gmupt_reset_stats */
     /* collect_stats only */
     uint64_t ext_rays, ext_inner, ext_leaves, ext_tris;
     uint64_t sh_rays, sh_inner, sh_leaves, sh_tris;
     /* device time per stage group in ms, accumulated since the last reset (HIP events on the renderer's stream; timing must be enabled) */
-    double ms_logic, ms_scan, ms_accumulate, ms_material, ms_extend, ms_shadow;
+    double ms_logic, ms_scan, ms_accumulate, ms_material, ms_extend, ms_shadow; /* ms_scan and ms_accumulate are always 0: the queue ranks
+                                    are computed inside the logic / material kernels and the accumulation inside the material kernel */
     uint64_t timed_iterations;
     /* collect_stats only: wave-level loop iterations of the ray casts; SIMD efficiency = lane steps / (64 * wave iterations) */
     uint64_t ext_wave_inner, ext_wave_tris, sh_wave_inner, sh_wave_tris;
@@ -176,6 +180,7 @@ typedef struct {
     uint64_t cast_drain_ticks, cast_drain_iters, cast_drain_busy_lanes; /* after a wave found both queues empty: ticks, loop iterations, busy lanes summed over them */
     uint64_t cast_wave_end_hist[32];  /* wave lifetimes in 50-us buckets */
     uint64_t ray_inner_hist[32];      /* extension rays by inner nodes visited, 16 per bucket */
+    uint64_t ext_top_inner, sh_top_inner; /* inner-node visits served by the LDS-resident top of the tree (k_cast_f, collect_stats) */
 } gmupt_stats;
 int gmupt_get_stats(gmupt_renderer* r, gmupt_stats* out); /* synchronises */
 int gmupt_reset_stats(gmupt_renderer* r);

@@ -11,6 +11,20 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Multi-process GPU tests start their ranks from a fork server that is created HERE, before anything in this process has
+    # touched the GPU: a process that has initialised HIP must not fork + exec children (the GPU box refuses that), and the
+    # server's children are plain forks of a process that never saw the device.
+    import multiprocessing as mp
+    from multiprocessing import forkserver
+    mp.get_context("forkserver")
+    forkserver.ensure_running()
+
+
+@pytest.fixture(scope="session")
+def clean_process_context():
+    """multiprocessing context whose children descend from the fork server started in pytest_configure."""
+    import multiprocessing as mp
+    return mp.get_context("forkserver")
 
 
 @pytest.fixture(scope="session")

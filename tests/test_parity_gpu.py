@@ -73,16 +73,50 @@ def test_iteration_parity(pkg, device, cornell_scene, soup_scene, spheres_small_
     hip.close(); sb.close(); orc.close()
 
 
-@pytest.mark.parametrize("mode", ["ref", "static", "whilewhile", "ifif1", "top", "coop", "def0", "def1", "pipe0", "cast1", "cast2", "cast3"])
-def test_every_traversal_rung_gives_the_same_bits(pkg, device, soup_scene, monkeypatch, mode):
-    # the ladder of ray-cast kernels kept for A/B timing (GMUPT_TRAVERSAL): every rung against the oracle
+@pytest.mark.parametrize("mode", ["ref", "static", "whilewhile", "ifif1", "top", "coop", "def0", "def1", "pipe0", "cast0", "cast1", "cast2", "cast3"])
+def test_every_traversal_rung_gives_the_same_bits(pkg, soup_scene, monkeypatch, mode):
+    # the ladder of ray-cast kernels kept for A/B timing (GMUPT_TRAVERSAL): every rung against the oracle.
+    # The rungs are only part of the -DGMUPT_VARIANTS test build of the library (libgmupt_variants.so); the shipped one has cast0 + def0.
     monkeypatch.setenv("GMUPT_TRAVERSAL", mode)
+    W, H, P = 48, 27, 4096
+    with pkg.capi.use_build("variants"):
+        dev = pkg.capi.Device(0)
+        orc, hip, ocam, hcam, sb = PU.make_pair(pkg, dev, soup_scene, W, H, P)
+        for it in range(14):
+            PU.step_both(orc, hip, ocam, hcam)
+        _assert_same(orc, hip, P, P, 14)
+        hip.close(); sb.close(); orc.close(); dev.close()
+
+
+def test_shipped_library_has_only_the_shipped_rungs(pkg, device, soup_scene, monkeypatch):
+    # the default build refuses a rung it does not contain instead of silently running another kernel
+    monkeypatch.setenv("GMUPT_TRAVERSAL", "coop")
+    with pytest.raises(pkg.capi.GmuptError, match="not part of this build"):
+        pkg.capi.Renderer(device, 16, 16, pool_paths=256)
+    monkeypatch.setenv("GMUPT_TRAVERSAL", "def0")
     W, H, P = 48, 27, 4096
     orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, soup_scene, W, H, P)
     for it in range(14):
         PU.step_both(orc, hip, ocam, hcam)
     _assert_same(orc, hip, P, P, 14)
+    assert (hip.stats().flags & pkg.capi.STAT_FUSED_CAST) == 0
     hip.close(); sb.close(); orc.close()
+
+
+def test_rank_computation_with_many_groups(pkg, spheres_small_scene):
+    # k_logic / k_material rank the queue entries in two levels: class counts per block, their totals per group of kScanGroup blocks.
+    # A block adds up the totals of the groups before its own with a loop strided by the block size (256): pools beyond 2^22 (config 5:
+    # 512 groups) take more than one trip.  The scan1 test build has one block per group, so a pool of 2^17 slots has 512 groups and
+    # reaches that path in seconds: state, queues, counters and framebuffer bit for bit against the oracle.
+    W, H, P = 160, 90, 1 << 17
+    with pkg.capi.use_build("scan1"):
+        dev = pkg.capi.Device(0)
+        orc, hip, ocam, hcam, sb = PU.make_pair(pkg, dev, spheres_small_scene, W, H, P, threads=16)
+        for it in range(8):
+            PU.step_both(orc, hip, ocam, hcam)
+            if it in (0, 1, 4, 7):
+                _assert_same(orc, hip, P, P, it)
+        hip.close(); sb.close(); orc.close(); dev.close()
 
 
 @pytest.mark.parametrize("knobs", [

@@ -1,23 +1,118 @@
-"""BASELINE config 5: ~10 M-triangle scene, 3840x2160, pool 2^23, max depth 16 -- HBM-bound stress run (steady-state stage times)."""
-import json, os, sys, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
-import numpy as np, gmupt_pkg
+"""BASELINE config 5 measured: ~10 M-triangle scene, 3840x2160, pool 2^23, max depth 16 -- the HBM-resident stress configuration.
+
+  python3 tools/config5.py [--steps 40] [--prewarm 60] [--count] [--cache /tmp/config5_scene.npz] [--out FILE] [--spheres 1953]
+
+Prints ONE JSON line: steady-state step time, per-stage HIP-event times, completed paths / s and -- with --count (a deterministic
+replay with the counting instantiation of the ray-cast kernel) -- the measured walk statistics (inner nodes I, triangle records T per
+ray of either kind, the share of node visits served by the LDS-resident tree top) and from them the records gathered per launch and
+per second.  `rocprofv3 --kernel-trace --stats` / `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` are run on this same command (program directly
+after `--`; tools/profile_config5.sh); their per-launch bytes divided by the launch time of THIS line is the HBM-side fraction.
+--cache keeps the built scene on disk so that the profiler passes of one GPU call do not rebuild it (9 s on 16 cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+import numpy as np
+import gmupt_pkg
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--spheres", type=int, default=1953)
+ap.add_argument("--subdiv", type=int, default=4)
+ap.add_argument("--width", type=int, default=3840)
+ap.add_argument("--height", type=int, default=2160)
+ap.add_argument("--pool", type=int, default=1 << 23)
+ap.add_argument("--max-depth", type=int, default=16)
+ap.add_argument("--prewarm", type=int, default=60, help="untimed iterations (max depth 16: the pool is in its steady state after ~3 generations)")
+ap.add_argument("--steps", type=int, default=40)
+ap.add_argument("--count", action="store_true", help="replay with the counting kernels: I, T, LDS share, records per launch")
+ap.add_argument("--cache", default="")
+ap.add_argument("--out", default="")
+args = ap.parse_args()
+
 g = gmupt_pkg.load(); capi = g.capi
-n_spheres = int(sys.argv[1]) if len(sys.argv) > 1 else 1953
-t = time.time(); mesh = g.scenes.spheres_mesh(n_spheres, 4, seed=1234); print("generated %d triangles in %.1f s" % (mesh["indices"].shape[0], time.time() - t), flush=True)
-t = time.time(); scene = g.scenes.build_scene(mesh); build_s = time.time() - t
-print("SBVH build + flatten %.1f s: %d nodes, %d references, depth %d, SAH %.1f" % (build_s, scene["nodes"].shape[0], scene["tris"].shape[0], scene["depth"], scene["sah"]), flush=True)
-dev = capi.Device(0); t = time.time(); sb = capi.SceneBuffers(dev, scene)
-W, H, P = 3840, 2160, 1 << 23
-r = capi.Renderer(dev, W, H, pool_paths=P, tile=(0, 0), max_depth=16, collect_stats=False); r.bind_scene(sb); print("upload + bind %.1f s" % (time.time() - t), flush=True)
-cam = capi.Camera(W, H); cam.set_pose(*scene["camera"])
-def step(n):
-    for _ in range(n): cam.update(0.0); r.set_camera(cam.buffer); r.iterate()
-step(60); r.synchronize(); r.reset_stats(); r.enable_timing(True)
-t = time.perf_counter(); step(40); r.synchronize(); dt = time.perf_counter() - t
-st = r.stats()
-out = {"config": "config5", "triangles": int(mesh["indices"].shape[0]), "nodes": int(scene["nodes"].shape[0]), "depth": scene["depth"], "build_s": round(build_s, 1),
-       "ms_per_step": round(dt / 40 * 1e3, 3), "mpaths_per_s": round(st.paths_completed / dt / 1e6, 2), "msegments_per_s": round(st.segments / dt / 1e6, 1),
-       "stage_ms": {k: round(getattr(st, "ms_" + k) / st.timed_iterations, 3) for k in ("logic", "scan", "material", "extend", "shadow")},
-       "stack_overflow": (st.flags & 1)}
-print(json.dumps(out), flush=True)
+KEYS = ("nodes", "tris", "verts", "props", "lights", "materials", "ref_triangle")
+t = time.time()
+if args.cache and os.path.exists(args.cache):
+    z = np.load(args.cache, allow_pickle=False)
+    scene = {k: z[k] for k in KEYS}
+    meta = json.loads(str(z["meta"]))
+    scene.update(meta); scene["camera"] = tuple(meta["camera"])
+    for k in ("tex_diffuse", "tex_metallic_roughness", "tex_normal"):
+        scene[k] = None
+    build_s = meta["build_s"]
+    print("scene from %s in %.1f s" % (args.cache, time.time() - t), file=sys.stderr, flush=True)
+else:
+    mesh = g.scenes.spheres_mesh(args.spheres, args.subdiv, seed=1234)
+    print("generated %d triangles in %.1f s" % (mesh["indices"].shape[0], time.time() - t), file=sys.stderr, flush=True)
+    t = time.time(); scene = g.scenes.build_scene(mesh); build_s = time.time() - t
+    print("SBVH build + flatten %.1f s: %d nodes, %d references, depth %d, SAH %.1f" % (build_s, scene["nodes"].shape[0], scene["tris"].shape[0], scene["depth"], scene["sah"]), file=sys.stderr, flush=True)
+    if args.cache:
+        meta = {"light_count": int(scene["light_count"]), "camera": [float(v) for v in scene["camera"]], "name": scene["name"], "sah": float(scene["sah"]),
+                "depth": int(scene["depth"]), "num_triangles": int(scene["num_triangles"]), "build_s": round(build_s, 2)}
+        np.savez(args.cache, meta=json.dumps(meta), **{k: scene[k] for k in KEYS})
+
+W, H, P = args.width, args.height, args.pool
+dev = capi.Device(0)
+t = time.time(); sb = capi.SceneBuffers(dev, scene)
+
+
+def make(stats):
+    r = capi.Renderer(dev, W, H, pool_paths=P, tile=(0, 0), max_depth=args.max_depth, collect_stats=stats)
+    r.bind_scene(sb)
+    cam = capi.Camera(W, H); cam.set_pose(*scene["camera"]); cam.buffer.lightCount = scene["light_count"]
+    return r, cam
+
+
+def step(r, cam, n):
+    for _ in range(n):
+        cam.update(0.0); r.set_camera(cam.buffer); r.iterate()
+
+
+r, cam = make(False)
+print("upload + bind %.1f s" % (time.time() - t), file=sys.stderr, flush=True)
+step(r, cam, args.prewarm); r.synchronize(); r.reset_stats(); r.enable_timing(1)
+t = time.perf_counter(); step(r, cam, args.steps); r.synchronize(); dt = time.perf_counter() - t
+st = r.stats(); r.enable_timing(0)
+n_inner = int((scene["nodes"]["isLeaf"] == 0).sum())
+out = {"config": "config5", "triangles": int(scene["num_triangles"]), "nodes": int(scene["nodes"].shape[0]), "references": int(scene["tris"].shape[0]), "depth": int(scene["depth"]),
+       "build_s": round(build_s, 1), "width": W, "height": H, "pool": P, "max_depth": args.max_depth, "prewarm": args.prewarm, "steps": args.steps,
+       "traversal_bytes": {"node64": n_inner * 64, "tri48": (int(scene["tris"].shape[0]) + 1) * 48},
+       "ms_per_step": round(dt / args.steps * 1e3, 4), "mpaths_per_s": round(st.paths_completed / dt / 1e6, 3), "msegments_per_s": round(st.segments / dt / 1e6, 1),
+       "stage_ms": {k: round(getattr(st, "ms_" + k) / st.timed_iterations, 4) for k in ("logic", "material", "extend", "shadow")},
+       "kernel_flags": {"fused_cast": bool(st.flags & capi.STAT_FUSED_CAST), "k_cast_f": bool(st.flags & capi.STAT_CAST_FETCH),
+                        "stack_spill_instantiation": bool(st.flags & capi.STAT_STACK_SPILL), "stack_overflow": bool(st.flags & capi.STAT_STACK_OVERFLOW)}}
+cast_ms = st.ms_extend / st.timed_iterations
+r.close()
+if args.count:
+    r2, cam2 = make(True)
+    step(r2, cam2, args.prewarm); r2.synchronize(); r2.reset_stats()
+    step(r2, cam2, args.steps); s2 = r2.stats(); r2.close()
+    k = float(args.steps)
+    top = s2.ext_top_inner + s2.sh_top_inner
+    node_recs = (s2.ext_inner + s2.sh_inner - top) / k          # 64-byte node records fetched from global memory per launch
+    tri_recs = (s2.ext_tris + s2.sh_tris) / k                  # 48-byte triangle records per launch
+    rays = (s2.ext_rays + s2.sh_rays) / k
+    # bytes the kernel's own algorithm moves per launch: every global node visit 64 B, every triangle test 48 B (40 B used), ray in / hit out per ray
+    ray_io = (s2.ext_rays * (4 + 24 + 48) + s2.sh_rays * (4 + 28 + 4)) / k
+    alg_bytes = node_recs * 64 + tri_recs * 48 + ray_io
+    # what the REFERENCE's kernels would read for the same walks (144 B per inner step, 52 B per triangle test)
+    ref_bytes = (s2.ext_rays * (4 + 24 + 48 + 32 * scene["light_count"] + 48) + 96 * s2.ext_inner + 52 * s2.ext_tris
+                 + s2.sh_rays * (4 + 24 + 4 + 48 + 4) + 96 * s2.sh_inner + 52 * s2.sh_tris) / k
+    out["cast"] = {"avg_launch_ms": round(cast_ms, 4), "rays_per_launch": rays, "ext_rays_per_launch": s2.ext_rays / k, "shadow_rays_per_launch": s2.sh_rays / k,
+                   "inner_per_ext_ray": round(s2.ext_inner / max(s2.ext_rays, 1), 2), "tris_per_ext_ray": round(s2.ext_tris / max(s2.ext_rays, 1), 2),
+                   "inner_per_shadow_ray": round(s2.sh_inner / max(s2.sh_rays, 1), 2), "tris_per_shadow_ray": round(s2.sh_tris / max(s2.sh_rays, 1), 2),
+                   "lds_top_share_of_node_visits": round(top / max(s2.ext_inner + s2.sh_inner, 1), 4),
+                   "global_records_per_launch": node_recs + tri_recs, "grecords_per_s": round((node_recs + tri_recs) / (cast_ms * 1e-3) / 1e9, 2),
+                   "kernel_bytes_per_launch": int(alg_bytes), "kernel_bytes_gbs": round(alg_bytes / (cast_ms * 1e-3) / 1e9, 1),
+                   "reference_equivalent_bytes_per_launch": int(ref_bytes)}
+line = json.dumps(out)
+print(line, flush=True)
+if args.out:
+    with open(args.out, "w") as f:
+        f.write(line + "\n")
+sb.close(); dev.close()

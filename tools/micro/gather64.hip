@@ -3,6 +3,9 @@
 //  B: the 4 lanes of a quad fetch the 4 quarters of one record (1 x dwordx4 per lane and record)        -> 16 records / instr
 //  C: as A but every lane of a quad reads the SAME record (coherent rays)                                -> 16 distinct records / 4 instr
 //  D: one lane fetches a 48-byte record (3 x dwordx4)
+//  E: as B, but through LDS-DMA (global_load_lds_dwordx4 with per-lane source addresses: instruction j brings the records of lanes 4g+j
+//     of every quad g into a per-wave staging region) and each lane reads its own record back with 4 x ds_read_b128 -- no register shuffles
+//  F: as A, 3 x dwordx4 + 1 x dwordx2 of a 64-byte record (what k_cast_f issues per node)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -35,6 +38,28 @@ __global__ __launch_bounds__(256) void k(const float4* __restrict__ recs, const 
             float4 a = p[0], b = p[1], c = p[2], d = p[3];
             acc += a.x + b.y + c.z + d.w;
             r = (__float_as_uint(d.x) + r * 1664525u + it) % n;
+        } else if (MODE == 4) {
+            typedef __attribute__((address_space(3))) void lds_void;
+            typedef const __attribute__((address_space(1))) void glb_void;
+            __shared__ __attribute__((aligned(16))) char s_stage[4][4 * (1024 + 64)];
+            char* stage = s_stage[threadIdx.x >> 6];
+            const char* base = reinterpret_cast<const char*>(recs) + 16u * (lane & 3u);
+            unsigned r0 = __shfl(r, (lane & ~3u) + 0), r1 = __shfl(r, (lane & ~3u) + 1), r2 = __shfl(r, (lane & ~3u) + 2), r3 = __shfl(r, (lane & ~3u) + 3);
+            __builtin_amdgcn_global_load_lds((glb_void*)(base + (size_t)r0 * 64u), (lds_void*)(stage + 0 * 1088), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(base + (size_t)r1 * 64u), (lds_void*)(stage + 1 * 1088), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(base + (size_t)r2 * 64u), (lds_void*)(stage + 2 * 1088), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(base + (size_t)r3 * 64u), (lds_void*)(stage + 3 * 1088), 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const float4* mine = reinterpret_cast<const float4*>(stage + (lane & 3u) * 1088 + (lane >> 2) * 64u);
+            float4 a = mine[0], b = mine[1], c = mine[2], d = mine[3];
+            acc += a.x + b.y + c.z + d.w;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the next round overwrites the staging region
+            r = (__float_as_uint(d.x) + r * 1664525u + it) % n;
+        } else if (MODE == 5) {
+            const float4* p = recs + 4ull * r;
+            float4 a = p[0], b = p[1], c = p[2]; float2 d = *reinterpret_cast<const float2*>(p + 3);
+            acc += a.x + b.y + c.z + d.y;
+            r = (__float_as_uint(d.x) + r * 1664525u + it) % n;
         } else {
             const float4* p = recs + 3ull * r;
             float4 a = p[0], b = p[1], c = p[2];
@@ -52,24 +77,28 @@ int main(int argc, char** argv)
     std::vector<float> h((size_t)n * 16);
     for (size_t i = 0; i < h.size(); i++) h[i] = (float)(rand() % 1000000);
     std::vector<unsigned> hi(threads);
-    for (auto& v : hi) v = rand() % n;
+    for (auto& v : hi) v = (unsigned)(((unsigned long long)rand() * 2147483648ull + (unsigned long long)rand()) % n);
     float4* recs; unsigned* idx; float* out;
     CHECK(hipMalloc(&recs, h.size() * 4)); CHECK(hipMalloc(&idx, hi.size() * 4)); CHECK(hipMalloc(&out, threads * 4));
     CHECK(hipMemcpy(recs, h.data(), h.size() * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(idx, hi.data(), hi.size() * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    const char* names[4] = { "A lane=record 4x16B", "B quad=record 1x16B x4 recs", "C quad shares record", "D lane=48B record" };
+    const char* names[6] = { "A lane=record 4x16B", "B quad=record 1x16B x4 recs", "C quad shares record", "D lane=48B record", "E quad=record via LDS-DMA", "F lane=record 3x16B+8B" };
+    printf("table: %u records of 64 B = %.1f MB\n", n, n * 64.0 / 1e6);
     for (int rep = 0; rep < 2; rep++)
-        for (int m = 0; m < 4; m++) {
+        for (int m = 0; m < 6; m++) {
             CHECK(hipEventRecord(e0));
             if (m == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, recs, idx, out, iters, n);
             if (m == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, recs, idx, out, iters, n);
             if (m == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, recs, idx, out, iters, n);
+            if (m == 4) hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), 0, 0, recs, idx, out, iters, n);
+            if (m == 5) hipLaunchKernelGGL(k<5>, dim3(blocks), dim3(256), 0, 0, recs, idx, out, iters, n);
             if (m == 3) hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), 0, 0, recs, idx, out, iters, n / 4 * 4 / 3);
             CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
             const double recsFetched = (double)threads * iters;
-            if (rep) printf("%-30s %8.3f ms  %7.1f Grec/s  %7.1f GB/s useful  (%.2f cycles/lane-record/CU)\n", names[m], ms, recsFetched / ms / 1e6,
-                            recsFetched * (m == 3 ? 48 : 64) / ms / 1e6, ms * 1e-3 * 2.4e9 * 256 / recsFetched);
+            const double lanereq = (m == 0 || m == 2 || m == 5) ? 4 : (m == 3 ? 3 : 4); // 16-byte (or 8-byte) lane requests per record
+            if (rep) printf("%-30s %8.3f ms  %7.1f Grec/s  %7.1f GB/s useful  %.3f lane-requests/clk/CU @2.4GHz  (%.2f cycles/lane-record/CU)\n", names[m], ms, recsFetched / ms / 1e6,
+                            recsFetched * (m == 3 ? 48 : 64) / ms / 1e6, recsFetched * lanereq / (ms * 1e-3 * 2.4e9 * 256), ms * 1e-3 * 2.4e9 * 256 / recsFetched);
         }
     return 0;
 }
