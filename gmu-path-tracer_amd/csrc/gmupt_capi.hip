@@ -863,8 +863,8 @@ extern "C" int gmupt_sbvh_build(const float* vertices, uint32_t num_vertices, co
     }
     return GMUPT_OK;
 }
-extern "C" uint32_t gmupt_sbvh_num_nodes(const gmupt_sbvh* h) { return h ? (uint32_t)h->b->nodes().size() : 0; }
-extern "C" uint32_t gmupt_sbvh_num_references(const gmupt_sbvh* h) { return h ? (uint32_t)h->b->refTriangles().size() : 0; }
+extern "C" uint32_t gmupt_sbvh_num_nodes(const gmupt_sbvh* h) { return h ? h->b->numNodes() : 0; }
+extern "C" uint32_t gmupt_sbvh_num_references(const gmupt_sbvh* h) { return h ? h->b->numReferences() : 0; }
 extern "C" float gmupt_sbvh_sah(const gmupt_sbvh* h) { return h ? h->b->sah() : 0.0f; }
 extern "C" uint32_t gmupt_sbvh_depth(const gmupt_sbvh* h) { return h ? h->b->depth() : 0; }
 extern "C" int gmupt_sbvh_flatten(const gmupt_sbvh* h, const uint32_t* vertex_material, gmupt_bvh_node* nodes, gmupt_triangle* triangles, int32_t* ref_triangle)

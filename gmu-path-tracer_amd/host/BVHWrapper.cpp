@@ -29,7 +29,7 @@ void BVHWrapper::buildSBVH(const MeshData& scene)
 	builder.build();
 	mSAH = builder.sah();
 
-	mGPUTree.resize(builder.nodes().size());
-	mIndices.resize(builder.refTriangles().size());
+	mGPUTree.resize(builder.numNodes());
+	mIndices.resize(builder.numReferences());
 	builder.flatten(scene.vertexMaterial.data(), mGPUTree.data(), mIndices.data(), nullptr);
 }

@@ -1,87 +1,53 @@
-// Host-side split-BVH builder (Stich, Friedrich, Dietrich: "Spatial Splits in Bounding
-// Volume Hierarchies", HPG 2009) that emits the reference's flattened buffers.
+// Host-side split-BVH builder (Stich, Friedrich, Dietrich: "Spatial Splits in Bounding Volume Hierarchies", HPG 2009) that emits the
+// reference's flattened buffers.  It takes the place of the vendored builder the reference drives from BVHWrapper::buildSBVH
+// (Source/BVHWrapper.cpp:13-96) and must produce THE SAME TREE for the reference's default Platform / BuildParams: SAH costs 1 / 1,
+// min leaf 1, no max leaf, splitAlpha 1e-5, max depth 64, spatial splits down to depth 48 with 32 bins
+// (Include/Nvidia-SBVH/SplitBVHBuilder.h:36-41, Include/Nvidia-SBVH/Util.h:73, Include/Nvidia-SBVH/BVH.h:72-78) -- node boxes, leaf
+// contents and the order of the references inside every leaf decide which hit wins an exact tie on the GPU.
 //
-// Replaces the vendored builder of the reference (Source/Nvidia-SBVH/SplitBVHBuilder.cpp,
-// driven by BVHWrapper::buildSBVH, Source/BVHWrapper.cpp:13-96).  It is a new
-// implementation (index-based node pool, std::sort, no virtual node classes); the split
-// decisions follow the same rules and the same reference-stack discipline, so that the
-// resulting tree is the one the reference's default Platform / BuildParams would build:
-//   SAH costs 1/1, min leaf 1, no max leaf, splitAlpha 1e-5, max depth 64, spatial
-//   splits down to depth 48 with 32 bins (Include/Nvidia-SBVH/SplitBVHBuilder.h:36-41,
-//   Include/Nvidia-SBVH/Util.h:73, Include/Nvidia-SBVH/BVH.h:72-78).
+// Design (host-first, nothing of the reference's program structure):
+//   * references are 32-byte records in a chunked, append-only pool; nodes never move them, they hold index lists;
+//   * every node task carries its references in THREE lists, pre-sorted along x, y and z by the reference's total order (centroid
+//     along the axis, then triangle id).  They are sorted ONCE for the root (parallel merge sort on 64-bit keys) and handed down the
+//     tree by stable partition; references created by a spatial split are sorted among themselves and merged in.  The SAH sweep of a
+//     node is three linear passes over those lists, not three sorts;
+//   * the tree is built by a pool of workers from a shared LIFO of node tasks (big nodes near the root also fan their sweeps,
+//     binning and partitions out over helper threads); subtrees below a size threshold are finished by the worker that owns them on a
+//     private stack.  Nodes live in per-worker arenas and are linked by pointers, so no numbering depends on the schedule; flatten()
+//     numbers them afterwards in the reference's order.
+// Which rule of the reference every step reproduces is cited in sbvh_builder.cpp.  The algorithm is the published one (HPG 2009); the
+// tie-breaking and arithmetic conventions that make the tree identical are those of the BSD-licensed implementation the reference
+// vendors (Copyright (c) 2009-2011, NVIDIA Corporation); none of its code is used here.
 #pragma once
 #include <cstdint>
-#include <vector>
+#include <memory>
 #include "../../include/gmupt.h"
 
 namespace gmupt {
 
-struct Aabb {
-    float mn[3], mx[3];
-    Aabb();
-    void grow(const float* p);
-    void grow(const Aabb& o);
-    void clip(const Aabb& o);
-    bool valid() const;
-    float area() const;
-};
-
-struct SbvhNode {
-    Aabb bounds;
-    int32_t child[2]; // -1 for a leaf
-    int32_t lo, hi;   // leaf: range in refTriangles
-};
-
 class SbvhBuilder {
 public:
-    SbvhBuilder(const float* vertices, uint32_t numVertices, const int32_t* indices, uint32_t numTriangles,
-                const gmupt_sbvh_params& params);
+    SbvhBuilder(const float* vertices, uint32_t numVertices, const int32_t* indices, uint32_t numTriangles, const gmupt_sbvh_params& params);
+    ~SbvhBuilder();
+    SbvhBuilder(const SbvhBuilder&) = delete;
+    SbvhBuilder& operator=(const SbvhBuilder&) = delete;
+
     void build();
 
-    const std::vector<SbvhNode>& nodes() const { return mNodes; }
-    int32_t root() const { return mRoot; }
-    const std::vector<int32_t>& refTriangles() const { return mRefTriangles; }
-    uint32_t numDuplicates() const { return mNumDuplicates; }
-    uint32_t depth() const { return mDepth; }
-    float sah() const;
+    uint32_t numNodes() const;
+    uint32_t numReferences() const;   // triangle references in all leaves (triangles + duplicates made by spatial splits)
+    uint32_t numDuplicates() const;
+    uint32_t depth() const;           // level of the deepest node, root = 0
+    float sah() const;                // expected traversal cost, summed as BVHNode::computeSubtreeProbabilities does (Source/Nvidia-SBVH/BVHNode.cpp:65-79)
 
-    // Reference layout (Source/BVHWrapper.cpp:56-95): root at 0, the two children of an inner node
-    // in consecutive slots (right == left + 1), leaves index a triangle array filled in DFS order.
+    // Reference layout (Source/BVHWrapper.cpp:56-95): root at 0, the two children of an inner node in consecutive slots
+    // (right == left + 1), leaves index a triangle array filled in depth-first order, left subtree first.
+    // outNodes: numNodes() records; outTris / outRefTri (either may be null): numReferences() entries.
     void flatten(const uint32_t* vertexMaterial, gmupt_bvh_node* outNodes, gmupt_triangle* outTris, int32_t* outRefTri) const;
 
 private:
-    struct Ref { int32_t tri; Aabb b; };
-    struct Spec { int32_t numRef; Aabb b; };
-    struct ObjSplit { float sah; int dim; int numLeft; Aabb lb, rb; };
-    struct SpaSplit { float sah; int dim; float pos; };
-
-    // sub-builder of one subtree: takes the top `numRef` references of the parent's stack (the parent keeps building the sibling on its
-    // own thread and absorbs the result afterwards).  The tree and every leaf's reference order are those of the sequential build.
-    SbvhBuilder(SbvhBuilder& parent, int numRef);
-    int32_t absorb(const SbvhBuilder& sub, int32_t subRoot);
-    int32_t buildNode(const Spec& spec, int level);
-    int32_t makeLeaf(const Spec& spec);
-    ObjSplit findObjectSplit(const Spec& spec, float nodeSAH);
-    void doObjectSplit(Spec& l, Spec& r, const Spec& spec, const ObjSplit& s);
-    SpaSplit findSpatialSplit(const Spec& spec, float nodeSAH);
-    void doSpatialSplit(Spec& l, Spec& r, const Spec& spec, const SpaSplit& s);
-    void splitRef(Ref& l, Ref& r, const Ref& ref, int dim, float pos) const;
-    void sortTail(int numRef, int dim);
-    float triCost(int n) const { return (float)n * mP.tri_cost; }
-
-    const float* mVerts;
-    const int32_t* mIdx;
-    uint32_t mNumTris;
-    gmupt_sbvh_params mP;
-
-    std::vector<Ref> mStack;
-    std::vector<Aabb> mRight;
-    std::vector<SbvhNode> mNodes;
-    std::vector<int32_t> mRefTriangles;
-    float mMinOverlap = 0.f;
-    uint32_t mNumDuplicates = 0;
-    uint32_t mDepth = 0;
-    int32_t mRoot = -1;
+    struct Impl;
+    std::unique_ptr<Impl> m;
 };
 
 } // namespace gmupt

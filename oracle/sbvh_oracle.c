@@ -3,8 +3,8 @@
  *
  * Plain-C restatement of the reference's host-side accel build: the vendored Nvidia split-BVH builder
  * (Source/Nvidia-SBVH/SplitBVHBuilder.cpp, default Platform / BuildParams) followed by BVHWrapper's flatten
- * (Source/BVHWrapper.cpp:56-95).  The product's builder (gmu-path-tracer_amd/host/sbvh_builder.cpp) is checked against
- * this node for node.
+ * (Source/BVHWrapper.cpp:56-95).  The product's builder (gmu-path-tracer_amd/host/sbvh_builder.cpp: a different program -- pre-sorted lists, task pool --
+ * that must arrive at the same tree) is checked against this node for node.
  *
  * PARITY UNPINNED against the reference binary: the reference builder cannot be compiled here without writing stand-ins
  * for <windows.h> (Source/Nvidia-SBVH/Timer.cpp:30, needed by SplitBVHBuilder's progress timer) and <DirectXMath.h>
@@ -12,6 +12,26 @@
  * restatements of the same rules agree.
  *
  * All citations are relative to /root/reference/.
+ *
+ * This file follows the structure of the vendored builder function by function (that is its purpose: a line-cited restatement to
+ * check the product's own builder against), so it carries that code's notice:
+ *
+ *   Copyright (c) 2009-2011, NVIDIA Corporation.  All rights reserved.
+ *
+ *   Redistribution and use in source and binary forms, with or without modification, are permitted provided that the following
+ *   conditions are met:
+ *     * Redistributions of source code must retain the above copyright notice, this list of conditions and the following disclaimer.
+ *     * Redistributions in binary form must reproduce the above copyright notice, this list of conditions and the following
+ *       disclaimer in the documentation and/or other materials provided with the distribution.
+ *     * Neither the name of NVIDIA Corporation nor the names of its contributors may be used to endorse or promote products derived
+ *       from this software without specific prior written permission.
+ *
+ *   THIS SOFTWARE IS PROVIDED BY THE COPYRIGHT HOLDERS AND CONTRIBUTORS "AS IS" AND ANY EXPRESS OR IMPLIED WARRANTIES, INCLUDING, BUT
+ *   NOT LIMITED TO, THE IMPLIED WARRANTIES OF MERCHANTABILITY AND FITNESS FOR A PARTICULAR PURPOSE ARE DISCLAIMED.  IN NO EVENT SHALL
+ *   THE COPYRIGHT HOLDER BE LIABLE FOR ANY DIRECT, INDIRECT, INCIDENTAL, SPECIAL, EXEMPLARY, OR CONSEQUENTIAL DAMAGES (INCLUDING, BUT
+ *   NOT LIMITED TO, PROCUREMENT OF SUBSTITUTE GOODS OR SERVICES; LOSS OF USE, DATA, OR PROFITS; OR BUSINESS INTERRUPTION) HOWEVER
+ *   CAUSED AND ON ANY THEORY OF LIABILITY, WHETHER IN CONTRACT, STRICT LIABILITY, OR TORT (INCLUDING NEGLIGENCE OR OTHERWISE) ARISING
+ *   IN ANY WAY OUT OF THE USE OF THIS SOFTWARE, EVEN IF ADVISED OF THE POSSIBILITY OF SUCH DAMAGE.
  */
 #include <float.h>
 #include <limits.h>

@@ -1,14 +1,38 @@
 #!/bin/bash
-# One-stop profile of the current build: bench JSON, rocprofv3 kernel stats, HBM traffic (two PMC passes).  Usage: tools/profile_round.sh <name>
+# One-stop profile of the current build.  Usage: tools/profile_round.sh <name> config3|config5   -> gpurun_out/<name>/
+#   run.json            the plain (un-profiled) measurement line: bench.py for config3, tools/config5.py --count for config5
+#   kernel_stats.csv    rocprofv3 --kernel-trace --stats of the same command (average launch durations)
+#   pmc_traffic.json    two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) summarised per launch by tools/pmc_summary.py
+#   pmc_counters.txt    per-kernel averages of the SQ / TCP / TCC / GRBM passes below (tools/pmc_table.py)
+# Every profiled command is the program itself after `--` (no env / bash -c hop), every pass has its own `timeout -k`, and a pass holds at most
+# as many counters of a block as the block has slots (MI355X_MICROARCH.md "rocprofv3 PMC slots"; an over-subscribed pass aborts the profiled
+# process: profiles/README.md "TA counter pass").
 export TMPDIR=/tmp
-NAME=${1:-r01_current}
+NAME=${1:?name}; MODE=${2:-config3}
 OUT=gpurun_out/$NAME
 mkdir -p $OUT
-python3 bench.py > $OUT/bench.log 2>&1; tail -1 $OUT/bench.log > $OUT/bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --no-roofline > $OUT/trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --prewarm 260 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --prewarm 260 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $OUT/write.log 2>&1
-grep -v '^W\|^I\|^E' $OUT/trace.log | tail -1 > $OUT/bench_under_rocprof.json
+if [ "$MODE" = config5 ]; then
+  timeout -k 10 500 python3 tools/config5.py --count --cache /tmp/config5_scene.npz --out $OUT/run.json > $OUT/run.log 2>&1 || { echo "plain run failed"; tail -5 $OUT/run.log; exit 1; }
+  CMD="python3 tools/config5.py --cache /tmp/config5_scene.npz"; SHORT="--prewarm 40 --steps 10"; SKIP=40
+else
+  timeout -k 10 500 python3 bench.py > $OUT/run.log 2>&1 || { echo "plain run failed"; tail -5 $OUT/run.log; exit 1; }
+  tail -1 $OUT/run.log > $OUT/run.json
+  CMD="python3 bench.py --no-cpu-baseline --no-roofline --no-full-frame"; SHORT="--prewarm 260 --steps 20 --warmup 5"; SKIP=265
+fi
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1 || { echo "trace pass failed"; tail -5 $OUT/trace.log; exit 1; }
 cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv
-python3 tools/pmc_summary.py $OUT/fetch $OUT/write $OUT/pmc_traffic.json > /dev/null
+grep -v '^W\|^I\|^E' $OUT/trace.log | tail -1 > $OUT/run_under_rocprof.json
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" \
+           "TCP_TOTAL_CACHE_ACCESSES TCP_TCC_READ_REQ TCP_PENDING_STALL_CYCLES TCP_TCP_TA_DATA_STALL_CYCLES" \
+           "TCC_HIT TCC_MISS TCC_REQ TCC_EA0_RDREQ" \
+           "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAVES" \
+           "SQ_INSTS_VMEM_RD SQ_INST_LEVEL_VMEM SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR" \
+           "GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  timeout -k 10 400 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc/pass$i -- $CMD $SHORT > $OUT/pmc_pass$i.log 2>&1 || { echo "pmc pass $i ($set) failed"; tail -3 $OUT/pmc_pass$i.log; exit 1; }
+done
+python3 tools/pmc_summary.py $OUT/pmc/pass1 $OUT/pmc/pass2 $OUT/pmc_traffic.json $SKIP > /dev/null
+python3 tools/pmc_table.py $OUT/pmc $SKIP > $OUT/pmc_counters.txt
+rm -rf $OUT/trace $OUT/pmc      # the raw per-dispatch CSVs stay on the box; the summaries above are what gets committed
 ls $OUT
