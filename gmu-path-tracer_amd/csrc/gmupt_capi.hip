@@ -386,8 +386,32 @@ static int build_traversal_copy(gmupt_renderer* r, const gmupt_buffer* nodesB, c
         }
         int32_t nextIdx = 0;
         for (int32_t v : bfs) innerIndex[(size_t)v] = nextIdx++;
-        for (size_t i = 0; i < N; i++) if (!nodes[i].isLeaf && innerIndex[i] < 0) innerIndex[i] = nextIdx++;
         r->p.trav.topCount = (uint32_t)bfs.size();
+        // The rest of the inner nodes.  Every memory-side read of the ray cast is a whole 128-byte line (TCC_EA0_RDREQ_128B is all of
+        // TCC_EA0_RDREQ: profiles/r02_micro/fetch_size_calibration.txt), i.e. TWO 64-byte records.  A node therefore shares its line with the
+        // inner child a ray is most likely to visit next (the one with the larger surface area): that visit then finds its record in the
+        // cache.  Nodes without such a partner share a line with the next one of their kind in flatten order (usually a sibling or cousin).
+        // GMUPT_NODE_PAIRING=0 keeps the plain flatten order (A/B timing; results do not depend on the numbering).
+        const char* pairing = std::getenv("GMUPT_NODE_PAIRING");
+        if (pairing && std::atoi(pairing) == 0) {
+            for (size_t i = 0; i < N; i++) if (!nodes[i].isLeaf && innerIndex[i] < 0) innerIndex[i] = nextIdx++;
+        } else {
+            auto area = [&](int32_t i) { const gmupt_bvh_node& n = nodes[(size_t)i]; const double dx = (double)n.max[0] - n.min[0], dy = (double)n.max[1] - n.min[1], dz = (double)n.max[2] - n.min[2]; return dx * dy + dy * dz + dz * dx; };
+            if (nextIdx & 1) nextIdx++;                                   // lines start at even records (an unused record keeps the parity)
+            std::vector<int32_t> partner(N, -1), singles;
+            std::vector<uint8_t> taken(N, 0);
+            for (size_t i = 0; i < N; i++) {                              // parents come before their children in the reference numbering
+                if (nodes[i].isLeaf || innerIndex[i] >= 0 || taken[i]) continue;
+                const int32_t l = nodes[i].left, rr = nodes[i].right;
+                const bool li = !nodes[(size_t)l].isLeaf && innerIndex[(size_t)l] < 0, ri = !nodes[(size_t)rr].isLeaf && innerIndex[(size_t)rr] < 0;
+                int32_t c = -1;
+                if (li && ri) c = area(l) >= area(rr) ? l : rr; else if (li) c = l; else if (ri) c = rr;
+                if (c >= 0) { partner[i] = c; taken[(size_t)c] = 1; } else singles.push_back((int32_t)i);
+            }
+            for (size_t i = 0; i < N; i++) if (partner[i] >= 0) { innerIndex[i] = nextIdx++; innerIndex[(size_t)partner[i]] = nextIdx++; }
+            for (int32_t v : singles) innerIndex[(size_t)v] = nextIdx++;
+        }
+        numInner = nextIdx;   // records of the packed array (one may be an unused filler)
     }
     for (size_t i = 0; i < R; i++)
         for (int k = 0; k < 3; k++)

@@ -34,7 +34,11 @@ std::vector<Taps> makeTaps(unsigned from, unsigned to)
 	std::vector<Taps> taps(to);
 	for (unsigned i = 0; i < to; i++)
 	{
-		const double center = (static_cast<double>(i) + 0.5) * scale - 0.5;
+		// geometry of avir's default resizing step (Include/avir/avir.h:4301-4324, k == 0): when ENLARGING, the centres of the first and the
+		// last pixel of source and destination coincide (step (from - 1) / (to - 1), no offset); when reducing, the images are aligned by
+		// their outer edges (step from / to, offset (step - 1) / 2)
+		const double center = to > from ? (to > 1 ? static_cast<double>(i) * (static_cast<double>(from) - 1.0) / (static_cast<double>(to) - 1.0) : 0.0)
+		                                : (static_cast<double>(i) + 0.5) * scale - 0.5;
 		const int lo = static_cast<int>(std::floor(center - 3.0 * stretch)) + 1, hi = static_cast<int>(std::floor(center + 3.0 * stretch));
 		Taps& t = taps[i]; t.first = lo;
 		double sum = 0.0;
