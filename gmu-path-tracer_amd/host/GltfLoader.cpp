@@ -1,19 +1,33 @@
-// Minimal glTF 2.0 reader producing what the reference gets from assimp with its post-process flags (Source/Scene.cpp:113-121):
-//   aiProcess_Triangulate (only TRIANGLES primitives are kept, like BVHWrapper.cpp:22), aiProcess_PreTransformVertices (node
-//   transforms baked into world-space vertices), aiProcess_GenSmoothNormals (only when a primitive has no normals),
-//   aiProcess_FlipUVs (v -> 1 - v), one material per primitive; material factors as read in Scene.cpp:130-146:
-//   baseColorFactor, metallicFactor, roughnessFactor, alphaMode == "BLEND" -> GLASS (Scene.cpp:138-143).
-// assimp itself is not available (headers only in the reference, binary .lib is an LFS stub), so this is a restatement of the
-// documented effect of those flags, not of assimp's code: PARITY UNPINNED.  Image decoding / texture
-// arrays: the loader only fetches the encoded image of every material's baseColorTexture / metallicRoughnessTexture / normalTexture
-// (assimp's aiTextureType_DIFFUSE / _UNKNOWN / _NORMALS for glTF 2.0); decoding and layer assignment happen in TextureLoader.cpp.
+// Minimal glTF 2.0 reader producing what the reference gets from assimp with its post-process flags (Source/Scene.cpp:113-121), as the
+// flags are documented in the assimp headers the reference vendors (Include/assimp/postprocess.h, config.h):
+//   aiProcess_Triangulate + SortByPType  only TRIANGLES primitives are kept (like BVHWrapper.cpp:22 ignores the other meshes);
+//   aiProcess_PreTransformVertices       node transforms baked into world-space vertices, the node graph flattened to one mesh per
+//                                        material (and vertex format): postprocess.h:207-222;
+//   aiProcess_GenSmoothNormals           only for meshes without authored normals: the face normals of all faces "at the same vertex
+//                                        position" are smoothed together, default angle limit 175 degrees = always (postprocess.h:169-183,
+//                                        config.h:163-173).  Weights are not documented; assimp's published step sums the UNIT face normals;
+//   aiProcess_JoinIdenticalVertices      "identifies and joins identical vertex data sets within all imported meshes"; without it "no
+//                                        vertices are referenced by more than one face" (postprocess.h:84-94): the pipeline works on one
+//                                        vertex per face corner and this step re-indexes them -- vertices come out in the order of their
+//                                        first use, duplicates (same position, normal, uv) are merged, also across the primitives that
+//                                        PreTransformVertices merged into one mesh;
+//   aiProcess_FlipUVs                    v -> 1 - v;
+//   material factors as read in Scene.cpp:130-146: baseColorFactor, metallicFactor, roughnessFactor, alphaMode == "BLEND" -> GLASS.
+// assimp itself is not available (headers only in the reference, its .lib is an LFS stub), so this restates the documented effect of
+// those flags, not assimp's code: PARITY UNPINNED -- positions, triangles and authored normals are exact by
+// construction; generated normals and the vertex numbering follow the documentation.  Image decoding / texture arrays: the loader only
+// fetches the encoded image of every material's baseColorTexture / metallicRoughnessTexture / normalTexture (assimp's
+// aiTextureType_DIFFUSE / _UNKNOWN / _NORMALS for glTF 2.0); decoding and layer assignment happen in TextureLoader.cpp.
 #include "MeshData.hpp"
 #include "json_min.hpp"
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <fstream>
+#include <map>
 #include <sstream>
 #include <stdexcept>
+#include <unordered_map>
 
 namespace {
 using gmupt::Json;
@@ -106,7 +120,11 @@ struct Gltf
 	}
 };
 
-void addPrimitive(const Gltf& g, const Json& prim, const Mat4& world, MeshData& out)
+// one vertex per face corner: the "verbose" form the post-process steps work on
+struct Corner { float p[3]; float n[3]; float uv[2]; };
+struct Part { uint32_t material; bool hasNormals, hasUV; std::vector<Corner> corners; };   // one glTF primitive, 3 corners per triangle
+
+void addPrimitive(const Gltf& g, const Json& prim, const Mat4& world, std::vector<Part>& parts)
 {
 	if (prim["mode"].integer(4) != 4) return; // only triangles are rendered (Source/BVHWrapper.cpp:21-23)
 	const Json& attrs = prim["attributes"];
@@ -133,47 +151,101 @@ void addPrimitive(const Gltf& g, const Json& prim, const Mat4& world, MeshData& 
 	for (int i = 0; i < n; i++)
 		for (int r = 0; r < 3; r++)
 			wp[static_cast<size_t>(i) * 3 + static_cast<size_t>(r)] = world.m[r] * pos[static_cast<size_t>(i) * 3] + world.m[4 + r] * pos[static_cast<size_t>(i) * 3 + 1] + world.m[8 + r] * pos[static_cast<size_t>(i) * 3 + 2] + world.m[12 + r];
-	// normals: transformed by the upper 3x3 (uniform scale assumed) or generated smooth (aiProcess_GenSmoothNormals)
+	// authored normals: transformed by the upper 3x3 (uniform scale assumed) and renormalised; under an identity transform they are kept bit
+	// for bit.  A primitive without normals gets them in finishMeshes (aiProcess_GenSmoothNormals works on the merged mesh).
 	std::vector<double> wn(static_cast<size_t>(n) * 3, 0.0);
 	if (nn == n && nc == 3) {
-		for (int i = 0; i < n; i++)
-			for (int r = 0; r < 3; r++)
-				wn[static_cast<size_t>(i) * 3 + static_cast<size_t>(r)] = world.m[r] * nrm[static_cast<size_t>(i) * 3] + world.m[4 + r] * nrm[static_cast<size_t>(i) * 3 + 1] + world.m[8 + r] * nrm[static_cast<size_t>(i) * 3 + 2];
-	} else {
-		for (size_t t = 0; t + 2 < idx.size(); t += 3) {
-			const double* a = &wp[static_cast<size_t>(idx[t]) * 3]; const double* b = &wp[static_cast<size_t>(idx[t + 1]) * 3]; const double* c = &wp[static_cast<size_t>(idx[t + 2]) * 3];
-			const double e1[3] = { b[0] - a[0], b[1] - a[1], b[2] - a[2] }, e2[3] = { c[0] - a[0], c[1] - a[1], c[2] - a[2] };
-			const double fn[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
-			for (int k = 0; k < 3; k++) for (int r = 0; r < 3; r++) wn[static_cast<size_t>(idx[t + static_cast<size_t>(k)]) * 3 + static_cast<size_t>(r)] += fn[r];
-		}
-	}
-	bool isIdentity = true;
-	{ const Mat4 id = identity(); for (int k = 0; k < 16; k++) isIdentity = isIdentity && world.m[k] == id.m[k]; }
-	if (!(isIdentity && nn == n && nc == 3)) // authored normals under an identity transform are kept bit for bit
+		bool isIdentity = true;
+		{ const Mat4 id = identity(); for (int k = 0; k < 16; k++) isIdentity = isIdentity && world.m[k] == id.m[k]; }
 		for (int i = 0; i < n; i++) {
 			double* v = &wn[static_cast<size_t>(i) * 3];
+			for (int r = 0; r < 3; r++)
+				v[r] = world.m[r] * nrm[static_cast<size_t>(i) * 3] + world.m[4 + r] * nrm[static_cast<size_t>(i) * 3 + 1] + world.m[8 + r] * nrm[static_cast<size_t>(i) * 3 + 2];
+			if (isIdentity) continue;
 			const double len = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
 			if (len > 0) { v[0] /= len; v[1] /= len; v[2] /= len; }
 		}
-
-	const uint32_t material = static_cast<uint32_t>(prim["material"].integer(0) < 0 ? 0 : prim["material"].integer(0));
-	const int32_t base = static_cast<int32_t>(out.numVertices());
-	const bool hadUV = !out.texCoords.empty() || base == 0;
-	for (int i = 0; i < n; i++) {
-		for (int r = 0; r < 3; r++) { out.vertices.push_back(static_cast<float>(wp[static_cast<size_t>(i) * 3 + static_cast<size_t>(r)])); out.normals.push_back(static_cast<float>(wn[static_cast<size_t>(i) * 3 + static_cast<size_t>(r)])); }
-		out.vertexMaterial.push_back(material);
 	}
-	(void)hadUV;
-	out.texCoords.resize(out.numVertices() * 2, 0.f);
-	if (un == n && uc == 2)
-		for (int i = 0; i < n; i++) {
-			out.texCoords[(static_cast<size_t>(base) + static_cast<size_t>(i)) * 2] = static_cast<float>(uv[static_cast<size_t>(i) * 2]);
-			out.texCoords[(static_cast<size_t>(base) + static_cast<size_t>(i)) * 2 + 1] = static_cast<float>(1.0 - uv[static_cast<size_t>(i) * 2 + 1]); // aiProcess_FlipUVs
-		}
-	for (int32_t i : idx) out.indices.push_back(base + i);
+
+	Part part;
+	part.material = static_cast<uint32_t>(prim["material"].integer(0) < 0 ? 0 : prim["material"].integer(0));
+	part.hasNormals = (nn == n && nc == 3);
+	part.hasUV = (un == n && uc == 2);
+	part.corners.reserve(idx.size());
+	for (int32_t i : idx) {
+		Corner c{};
+		for (int r = 0; r < 3; r++) { c.p[r] = static_cast<float>(wp[static_cast<size_t>(i) * 3 + static_cast<size_t>(r)]); c.n[r] = part.hasNormals ? static_cast<float>(wn[static_cast<size_t>(i) * 3 + static_cast<size_t>(r)]) : 0.f; }
+		if (part.hasUV) { c.uv[0] = static_cast<float>(uv[static_cast<size_t>(i) * 2]); c.uv[1] = static_cast<float>(1.0 - uv[static_cast<size_t>(i) * 2 + 1]); } // aiProcess_FlipUVs
+		part.corners.push_back(c);
+	}
+	parts.push_back(std::move(part));
 }
 
-void visitNode(const Gltf& g, int nodeIndex, const Mat4& parent, MeshData& out, int depth)
+struct Bits3 { uint32_t v[3]; bool operator==(const Bits3& o) const { return v[0] == o.v[0] && v[1] == o.v[1] && v[2] == o.v[2]; } };
+struct Bits8 { uint32_t v[8]; bool operator==(const Bits8& o) const { return std::memcmp(v, o.v, sizeof(v)) == 0; } };
+template <typename T> struct BitsHash { size_t operator()(const T& k) const { size_t h = 1469598103934665603ull; for (uint32_t w : k.v) { h ^= w; h *= 1099511628211ull; } return h; } };
+inline uint32_t floatKey(float f) { f += 0.0f; uint32_t u; std::memcpy(&u, &f, 4); return u; }   // -0 and +0 are the same coordinate
+
+// aiProcess_GenSmoothNormals on one mesh in verbose form: every corner gets the normalised sum of the unit normals of all faces that have a
+// corner at the same position
+void smoothNormals(std::vector<Corner>& corners)
+{
+	std::unordered_map<Bits3, size_t, BitsHash<Bits3>> slot;
+	std::vector<float> sum;
+	std::vector<size_t> slotOf(corners.size());
+	for (size_t i = 0; i < corners.size(); i++) {
+		const Bits3 key = { { floatKey(corners[i].p[0]), floatKey(corners[i].p[1]), floatKey(corners[i].p[2]) } };
+		auto it = slot.find(key);
+		if (it == slot.end()) { it = slot.emplace(key, sum.size() / 3).first; sum.insert(sum.end(), { 0.f, 0.f, 0.f }); }
+		slotOf[i] = it->second;
+	}
+	for (size_t t = 0; t + 2 < corners.size(); t += 3) {
+		const float* a = corners[t].p; const float* b = corners[t + 1].p; const float* c = corners[t + 2].p;
+		const float e1[3] = { b[0] - a[0], b[1] - a[1], b[2] - a[2] }, e2[3] = { c[0] - a[0], c[1] - a[1], c[2] - a[2] };
+		float fn[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
+		const float len = std::sqrt(fn[0] * fn[0] + fn[1] * fn[1] + fn[2] * fn[2]);
+		if (len > 0.f) { fn[0] /= len; fn[1] /= len; fn[2] /= len; }
+		for (int k = 0; k < 3; k++) for (int r = 0; r < 3; r++) sum[slotOf[t + static_cast<size_t>(k)] * 3 + static_cast<size_t>(r)] += fn[r];
+	}
+	for (size_t i = 0; i < corners.size(); i++) {
+		const float* v = &sum[slotOf[i] * 3];
+		const float len = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+		for (int r = 0; r < 3; r++) corners[i].n[r] = len > 0.f ? v[r] / len : v[r];
+	}
+}
+
+// PreTransformVertices' mesh merge, GenSmoothNormals and JoinIdenticalVertices over the collected primitives -> the indexed MeshData
+void finishMeshes(std::vector<Part>& parts, MeshData& out)
+{
+	// one mesh per (material, vertex format), materials in ascending order, formats in order of first appearance
+	std::map<uint32_t, std::vector<size_t>> byMaterial;
+	for (size_t i = 0; i < parts.size(); i++) byMaterial[parts[i].material].push_back(i);
+	bool anyUV = false;
+	for (const Part& p : parts) anyUV = anyUV || p.hasUV;
+	for (auto& entry : byMaterial) {
+		std::vector<std::pair<bool, bool>> formats;
+		for (size_t i : entry.second) { const std::pair<bool, bool> f{ parts[i].hasNormals, parts[i].hasUV }; if (std::find(formats.begin(), formats.end(), f) == formats.end()) formats.push_back(f); }
+		for (const auto& f : formats) {
+			std::vector<Corner> corners;
+			for (size_t i : entry.second) if (parts[i].hasNormals == f.first && parts[i].hasUV == f.second) corners.insert(corners.end(), parts[i].corners.begin(), parts[i].corners.end());
+			if (!f.first) smoothNormals(corners);
+			std::unordered_map<Bits8, int32_t, BitsHash<Bits8>> joined;
+			for (const Corner& c : corners) {
+				const Bits8 key = { { floatKey(c.p[0]), floatKey(c.p[1]), floatKey(c.p[2]), floatKey(c.n[0]), floatKey(c.n[1]), floatKey(c.n[2]), floatKey(c.uv[0]), floatKey(c.uv[1]) } };
+				auto it = joined.find(key);
+				if (it == joined.end()) {
+					it = joined.emplace(key, static_cast<int32_t>(out.numVertices())).first;
+					for (int r = 0; r < 3; r++) { out.vertices.push_back(c.p[r]); out.normals.push_back(c.n[r]); }
+					if (anyUV) { out.texCoords.push_back(c.uv[0]); out.texCoords.push_back(c.uv[1]); }
+					out.vertexMaterial.push_back(entry.first);
+				}
+				out.indices.push_back(it->second);
+			}
+		}
+	}
+}
+
+void visitNode(const Gltf& g, int nodeIndex, const Mat4& parent, std::vector<Part>& out, int depth)
 {
 	if (depth > 64) throw std::runtime_error("glTF: node hierarchy too deep");
 	const Json& node = g.doc["nodes"][static_cast<size_t>(nodeIndex)];
@@ -261,8 +333,10 @@ MeshData MeshData::loadGltf(const std::string& path)
 	if (out.materials.empty()) { gmupt_material mp{}; mp.color[0] = mp.color[1] = mp.color[2] = 0.6f; mp.color[3] = 1.f; mp.metallic = 0.f; mp.roughness = 1.f; mp.textureIndices[0] = mp.textureIndices[1] = mp.textureIndices[2] = -1; out.materials.push_back(mp); }
 	const Json& scenes = g.doc["scenes"];
 	const Json& scene = scenes[static_cast<size_t>(g.doc["scene"].integer(0) < 0 ? 0 : g.doc["scene"].integer(0))];
-	if (scene.type == Json::Object) for (size_t i = 0; i < scene["nodes"].size(); i++) visitNode(g, scene["nodes"][i].integer(0), identity(), out, 0);
-	else for (size_t i = 0; i < g.doc["nodes"].size(); i++) visitNode(g, static_cast<int>(i), identity(), out, 0);
+	std::vector<Part> parts;
+	if (scene.type == Json::Object) for (size_t i = 0; i < scene["nodes"].size(); i++) visitNode(g, scene["nodes"][i].integer(0), identity(), parts, 0);
+	else for (size_t i = 0; i < g.doc["nodes"].size(); i++) visitNode(g, static_cast<int>(i), identity(), parts, 0);
+	finishMeshes(parts, out);
 	for (uint32_t& m : out.vertexMaterial) if (m >= out.materials.size()) m = 0;
 	if (out.numTriangles() == 0) throw std::runtime_error("glTF: no triangles in " + path);
 	return out;

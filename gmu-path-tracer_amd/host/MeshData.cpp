@@ -40,6 +40,19 @@ MeshData MeshData::load(const std::string& path)
 	return m;
 }
 
+void MeshData::save(const std::string& path) const
+{
+	File file{ std::fopen(path.c_str(), "wb") };
+	if (!file.f) throw std::runtime_error("Cannot write " + path);
+	const uint32_t hdr[4] = { static_cast<uint32_t>(numVertices()), static_cast<uint32_t>(numTriangles()), static_cast<uint32_t>(materials.size()), texCoords.empty() ? 0u : 1u };
+	bool ok = std::fwrite("GMESH001", 1, 8, file.f) == 8 && std::fwrite(hdr, 4, 4, file.f) == 4;
+	auto put = [&](const void* data, size_t bytes) { ok = ok && (bytes == 0 || std::fwrite(data, 1, bytes, file.f) == bytes); };
+	put(vertices.data(), vertices.size() * 4); put(normals.data(), normals.size() * 4);
+	if (!texCoords.empty()) put(texCoords.data(), texCoords.size() * 4);
+	put(vertexMaterial.data(), vertexMaterial.size() * 4); put(indices.data(), indices.size() * 4); put(materials.data(), materials.size() * sizeof(gmupt_material));
+	if (!ok) throw std::runtime_error("Cannot write " + path);
+}
+
 MeshData MeshData::cornell()
 {
 	MeshData m;

@@ -24,6 +24,8 @@ struct MeshData
 
 	// ".gmesh": little-endian dump written by gmu-path-tracer_amd/scenes.py (save_gmesh); throws std::runtime_error
 	static MeshData load(const std::string& path);
+	// writes the same ".gmesh" format (what a loader produced, for inspection and for the tests that feed it to the oracle)
+	void save(const std::string& path) const;
 	// glTF 2.0 (.gltf + external .bin or base64 buffers, or a .glb container): triangulated, pre-transformed, smooth normals, flipped UVs -- the effect of the
 	// reference's assimp flags (Source/Scene.cpp:113-121); throws std::runtime_error
 	static MeshData loadGltf(const std::string& path);

@@ -1,11 +1,60 @@
 #include "Scene.hpp"
 #include "CsvParser.hpp"
+#include <algorithm>
+#include <filesystem>
 #include <fstream>
 #include <stdexcept>
 #include <thread>
 
 namespace {
 void check(int rc) { if (rc != GMUPT_OK) throw std::runtime_error(gmupt_last_error()); }
+}
+
+SceneParams SceneParams::instance = SceneParams();
+
+void SceneParams::loadScenes(const std::string& root)
+{
+	modelsRoot = root;
+	if (!modelsRoot.empty() && modelsRoot.back() != '/' && modelsRoot.back() != '\\') modelsRoot += '/';
+	loadScenes();
+}
+
+void SceneParams::loadScenes()
+{
+	namespace fs = std::filesystem;
+	pathNames.clear(); pathsReference.clear(); lights.clear(); cameraParams.clear();
+	mLoaded = true;
+	std::error_code ec;
+	if (fs::is_directory(modelsRoot, ec)) {
+		std::vector<std::string> found;
+		for (const auto& f : fs::recursive_directory_iterator(modelsRoot, ec)) {
+			if (!f.is_regular_file()) continue;
+			const std::string ext = f.path().extension().string();
+			if (ext == ".gltf" || ext == ".glb") found.push_back(f.path().string());
+		}
+		std::sort(found.begin(), found.end());   // the reference lists in directory-walk order (unspecified); sorted here so that indices are stable
+		for (const std::string& full : found) {
+			pathNames.emplace_back(full.substr(modelsRoot.size()));                       // Scene.cpp:30: name relative to the models directory
+			const Entry e = load(full.substr(0, full.find_last_of('.')) + ".params");     // :34-62
+			lights.push_back(e.lights);
+			cameraParams.push_back(e.camera);
+		}
+	}
+	for (const auto& p : pathNames) pathsReference.emplace_back(p.c_str());              // :67-68
+}
+
+bool SceneParams::contains(const std::string& name)
+{
+	if (!mLoaded) loadScenes();
+	return std::find(pathNames.begin(), pathNames.end(), name) != pathNames.end();
+}
+
+size_t SceneParams::getSceneIndex(const std::string& name)
+{
+	if (!mLoaded) loadScenes();
+	for (size_t i = 0; i < pathNames.size(); ++i)
+		if (name == pathNames[i]) return i;
+	throw std::runtime_error("Non existing scene " + name);                              // Scene.cpp:79
 }
 
 SceneParams::Entry SceneParams::load(const std::string& paramsPath)
@@ -41,21 +90,41 @@ Scene::Scene(gmupt_device* device, const std::string& path)
 	: mDevice(device)
 	, mSceneName(path)
 {
+	// Scene.cpp:85: the scene's name is its path below the models directory
+	SceneParams& registry = SceneParams::instance;
+	const bool belowRoot = !registry.modelsRoot.empty() && path.compare(0, registry.modelsRoot.size(), registry.modelsRoot) == 0;
+	if (belowRoot) mSceneName = path.substr(registry.modelsRoot.size());
+
 	loadScene(path);
 
-	std::thread worker(&Scene::createBVH, this); // as Source/Scene.cpp:89: BVH build + upload on a worker thread
-	loadTextures(); // decodes / resizes / uploads the three texture arrays on three threads, then uploads the material table
+	std::exception_ptr bvhError;                 // as Source/Scene.cpp:89: BVH build + upload on a worker thread
+	std::thread worker([&]() { try { createBVH(); } catch (...) { bvhError = std::current_exception(); } });
+	try
+	{
+		loadTextures(); // decodes / resizes / uploads the three texture arrays on three threads, then uploads the material table
 
-	std::string paramsPath = path;
-	const auto dot = paramsPath.find_last_of('.');
-	paramsPath = (dot == std::string::npos ? paramsPath : paramsPath.substr(0, dot)) + ".params";
-	const auto params = SceneParams::load(paramsPath);
-	createLights(params.lights);
+		SceneParams::Entry params;
+		if (belowRoot)
+		{
+			const size_t index = registry.getSceneIndex(mSceneName);   // Scene.cpp:95,315; throws "Non existing scene" like the reference
+			params.camera = registry.cameraParams[index]; params.lights = registry.lights[index];
+		}
+		else
+		{
+			std::string paramsPath = path;
+			const auto dot = paramsPath.find_last_of('.');
+			paramsPath = (dot == std::string::npos ? paramsPath : paramsPath.substr(0, dot)) + ".params";
+			params = SceneParams::load(paramsPath);
+		}
+		createLights(params.lights);
 
-	mCamera.setPosition(params.camera.position[0], params.camera.position[1], params.camera.position[2]);
-	mCamera.setRotation(params.camera.pitch, params.camera.yaw);
+		mCamera.setPosition(params.camera.position[0], params.camera.position[1], params.camera.position[2]);
+		mCamera.setRotation(params.camera.pitch, params.camera.yaw);
+	}
+	catch (...) { worker.join(); throw; }
 
 	worker.join();
+	if (bvhError) std::rethrow_exception(bvhError);
 }
 
 void Scene::update(float dt)

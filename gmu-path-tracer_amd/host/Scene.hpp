@@ -13,13 +13,34 @@
 using Light = gmupt_light;                   // Include/Scene.hpp:13-19
 using MaterialProperty = gmupt_material;     // Include/Scene.hpp:43-68
 
+// The reference's registry of scenes (Include/Scene.hpp:21-41, Source/Scene.cpp:22-80): every *.gltf below the models directory with the
+// camera pose and lights of its sibling .params file (or the defaults).  Differences: the models directory is a settable path (the
+// reference hard-codes "Assets\\Models\\" relative to the working directory), names use the platform's separator, .glb files are listed
+// too, and the registry is filled on first use instead of during static initialisation.
 struct SceneParams
 {
 	struct CameraParam { float position[3]; float pitch; float yaw; };
 	struct Entry { std::vector<Light> lights; CameraParam camera; };
+
+	void loadScenes();                                   // scans modelsRoot recursively (Scene.cpp:22-73); replaces the current lists
+	void loadScenes(const std::string& root);            // the same after modelsRoot = root
+	size_t getSceneIndex(const std::string& name);       // name relative to modelsRoot; throws std::runtime_error("Non existing scene <name>") (Scene.cpp:75-80)
+	bool contains(const std::string& name);
+
+	std::vector<std::string> pathNames;                  // scene names relative to modelsRoot, in directory-walk order
+	std::vector<const char*> pathsReference;             // the same as C strings (GUI.cpp:72 hands them to its combo box)
+	std::vector<std::vector<Light>> lights;
+	std::vector<CameraParam> cameraParams;
+	std::string modelsRoot = "Assets/Models/";
+
+	static SceneParams instance;
+
 	// row 0 = camera (x,y,z,pitch,yaw), rows 1.. = lights (x,y,z,falloff,r,g,b,radius); defaults if the file is missing
 	// (Source/Scene.cpp:34-62)
 	static Entry load(const std::string& paramsPath);
+
+private:
+	bool mLoaded = false;
 };
 
 struct BufferDeleter { void operator()(gmupt_buffer* b) const { gmupt_buffer_destroy(b); } };
@@ -29,7 +50,8 @@ class Scene
 {
 public:
 	Scene() = default;
-	// path: "<dir>/<name>.gmesh" with an optional sibling "<name>.params", or the built-in "cornell"
+	// path: a .gltf / .glb file.  Below SceneParams::instance.modelsRoot its camera / lights come from the registry, as in the reference
+	// (Scene.cpp:95,315); elsewhere (and for a ".gmesh" dump or the built-in "cornell") from the sibling "<name>.params" or the defaults.
 	Scene(gmupt_device* device, const std::string& path);
 
 	Scene(Scene&) = delete;

@@ -1,6 +1,8 @@
 // Headless driver of the C++ host classes: the reference's Window::loop (Source/Window.cpp:60-90: update(dt); draw();)
 // without a window.  Used by tests/test_host_cpp_gpu.py.
-//   gmupt_render --scene cornell|file.gmesh --size WxH --frames N --pool P --live L [--capture] [--dump out.f32] [--pfm out.pfm] [--build-only]
+//   gmupt_render --scene cornell|file.gmesh|file.gltf|file.glb --size WxH --frames N --pool P --live L [--capture] [--dump out.f32] [--pfm out.pfm]
+//                [--build-only] [--dump-mesh out.gmesh]   (what the loader produced, for the tests that feed it to the oracle)
+//                [--models-root DIR] [--list-scenes]      (SceneParams registry of the reference, Source/Scene.cpp:22-80)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -13,7 +15,8 @@
 
 int main(int argc, char** argv)
 {
-	std::string scene = "cornell", dump, pfm;
+	std::string scene = "cornell", dump, pfm, dumpMesh;
+	bool listScenes = false;
 	unsigned w = WIDTH, h = HEIGHT, frames = 16, pool = PATHCOUNT, live = REFERENCE_LIVE_PATHS;
 	bool capture = false, buildOnly = false;
 	std::string paramsOnly;
@@ -30,6 +33,9 @@ int main(int argc, char** argv)
 		else if (a == "--capture") capture = true;
 		else if (a == "--build-only") buildOnly = true;
 		else if (a == "--params") paramsOnly = next();
+		else if (a == "--dump-mesh") dumpMesh = next();
+		else if (a == "--models-root") SceneParams::instance.loadScenes(next());
+		else if (a == "--list-scenes") listScenes = true;
 		else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
 	}
 	try
@@ -44,9 +50,26 @@ int main(int argc, char** argv)
 			std::printf("]}\n");
 			return 0;
 		}
+		if (listScenes) { // the registry: name, camera, number of lights per scene below the models directory
+			SceneParams& reg = SceneParams::instance;
+			reg.contains("");
+			std::printf("[");
+			for (size_t i = 0; i < reg.pathNames.size(); i++) {
+				const auto& c = reg.cameraParams[i];
+				std::printf("%s{\"name\": \"%s\", \"index\": %zu, \"camera\": [%.9g, %.9g, %.9g, %.9g, %.9g], \"lights\": %zu}", i ? ", " : "", reg.pathsReference[i], reg.getSceneIndex(reg.pathNames[i]),
+				            c.position[0], c.position[1], c.position[2], c.pitch, c.yaw, reg.lights[i].size());
+			}
+			std::printf("]\n");
+			return 0;
+		}
 		if (buildOnly) { // host-only leg (BASELINE config 1): scene load + SBVH build + flatten, no GPU
 			const bool gltf = (scene.size() > 5 && scene.compare(scene.size() - 5, 5, ".gltf") == 0) || (scene.size() > 4 && scene.compare(scene.size() - 4, 4, ".glb") == 0);
+			{ // like Scene::Scene: a scene below the models directory must be one the registry knows (Source/Scene.cpp:75-80,95)
+				SceneParams& reg = SceneParams::instance;
+				if (!reg.modelsRoot.empty() && scene.compare(0, reg.modelsRoot.size(), reg.modelsRoot) == 0) reg.getSceneIndex(scene.substr(reg.modelsRoot.size()));
+			}
 			MeshData mesh = (scene == "cornell") ? MeshData::cornell() : gltf ? MeshData::loadGltf(scene) : MeshData::load(scene);
+			if (!dumpMesh.empty()) mesh.save(dumpMesh);
 			// texture ingestion without the upload: layers, common size and checksum per texture type (Scene.cpp:209-244,268-285)
 			std::string texInfo = "[";
 			for (int t = 0; t < 3; t++) {

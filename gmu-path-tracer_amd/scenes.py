@@ -270,6 +270,27 @@ def save_gmesh(mesh, path, params_path=None):
                 f.write(", ".join(repr(float(v)) for v in row) + "\n")
 
 
+def load_gmesh(path):
+    """Reads a ".gmesh" dump (save_gmesh above, or gmupt_render --dump-mesh = what the C++ scene loader produced) as a mesh dict
+    without camera / lights."""
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"GMESH001"
+    nv, nt, nm, has_uv = np.frombuffer(raw, np.uint32, 4, 8)
+    off = 24
+    def take(dtype, count):
+        nonlocal off
+        a = np.frombuffer(raw, dtype, count, off).copy()
+        off += a.nbytes
+        return a
+    mesh = {"verts": take(np.float32, nv * 3).reshape(-1, 3), "normals": take(np.float32, nv * 3).reshape(-1, 3)}
+    if has_uv:
+        mesh["uv"] = take(np.float32, nv * 2).reshape(-1, 2)
+    mesh["vertex_material"] = take(np.uint32, nv)
+    mesh["indices"] = take(np.int32, nt * 3).reshape(-1, 3)
+    mesh["materials"] = take(capi.material_dtype, nm)
+    return mesh
+
+
 def encode_png_rgba8(rgba):
     """Minimal PNG writer (RGBA, 8 bit, filter 0, zlib) for the texture files of save_gltf."""
     import struct, zlib

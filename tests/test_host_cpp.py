@@ -31,26 +31,120 @@ def test_build_only_matches_python_builder(exe, pkg, cornell_scene, tmp_path):
     assert out["nodes"] == ref["nodes"].shape[0] and out["references"] == ref["tris"].shape[0] and abs(out["sah"] - ref["sah"]) < 1e-3
 
 
+def _loaded(exe, pkg, path, tmp_path, name="loaded.gmesh"):
+    """What the C++ scene loader makes of a file: (--build-only summary, mesh dict)."""
+    dump = str(tmp_path / name)
+    out = json.loads(subprocess.run([exe, "--build-only", "--scene", path, "--dump-mesh", dump], check=True, capture_output=True, text=True).stdout)
+    return out, pkg.scenes.load_gmesh(dump)
+
+
+def _expected_smooth_normals(verts, indices, vertex_material):
+    """aiProcess_GenSmoothNormals as documented (postprocess.h:169-183): per mesh (= material), the normalised sum of the unit normals of all
+    faces with a corner at the same position.  Returns one normal per face corner (n_tris, 3, 3), float32 arithmetic like the loader."""
+    tri = verts[indices].astype(np.float32)
+    fn = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]).astype(np.float32)
+    ln = np.sqrt((fn * fn).sum(1, dtype=np.float32)).astype(np.float32)
+    fn = np.where(ln[:, None] > 0, fn / np.where(ln[:, None] > 0, ln[:, None], 1), fn).astype(np.float32)
+    sums = {}
+    mats = vertex_material[indices[:, 0]]
+    for t in range(indices.shape[0]):
+        for k in range(3):
+            key = (int(mats[t]),) + tuple((tri[t, k] + np.float32(0)).tolist())
+            sums[key] = sums.get(key, np.zeros(3, np.float32)) + fn[t]
+    out = np.zeros((indices.shape[0], 3, 3), np.float32)
+    for t in range(indices.shape[0]):
+        for k in range(3):
+            v = sums[(int(mats[t]),) + tuple((tri[t, k] + np.float32(0)).tolist())]
+            l = np.sqrt((v * v).sum(dtype=np.float32))
+            out[t, k] = v / l if l > 0 else v
+    return out
+
+
 def test_gltf_loader_matches_written_mesh(exe, pkg, tmp_path):
     # f1: Scene(device, "x.gltf") path -- geometry, material factors, BLEND -> glass, flipped UVs, .params sibling
     mesh = pkg.scenes.random_triangles_mesh(1500, seed=4)      # three materials, one of them glass
     path = str(tmp_path / "scene.gltf")
     written = pkg.scenes.save_gltf(mesh, path)
-    out = json.loads(subprocess.run([exe, "--build-only", "--scene", path], check=True, capture_output=True, text=True).stdout)
+    out, loaded = _loaded(exe, pkg, path, tmp_path)
     ref = pkg.scenes.build_scene(written)
-    assert out["triangles"] == written["indices"].shape[0] and out["vertices"] == written["verts"].shape[0]
+    assert out["triangles"] == written["indices"].shape[0] == loaded["indices"].shape[0]
+    # same triangles in the same order: corner positions, authored normals, flipped-back UVs and materials, bit for bit
+    for key in ("verts", "normals", "uv"):
+        assert np.array_equal(loaded[key][loaded["indices"]], written[key][written["indices"]].astype(np.float32)), key
+    assert np.array_equal(loaded["vertex_material"][loaded["indices"]], written["vertex_material"][written["indices"]])
+    # aiProcess_JoinIdenticalVertices: no two vertices of a mesh carry the same data, and they are numbered in the order of their first use
+    rec = np.concatenate([loaded["verts"], loaded["normals"], loaded["uv"], loaded["vertex_material"][:, None].astype(np.float32)], axis=1)
+    assert np.unique(rec, axis=0).shape[0] == rec.shape[0]
+    first_use = loaded["indices"].reshape(-1)
+    _, where = np.unique(first_use, return_index=True)
+    assert np.array_equal(first_use[np.sort(where)], np.arange(rec.shape[0]))
     assert out["materials"] == mesh["materials"].shape[0] and out["glass_materials"] == int((mesh["materials"]["materialType"] == 1).sum()) > 0
     assert out["nodes"] == ref["nodes"].shape[0] and out["references"] == ref["tris"].shape[0] and abs(out["sah"] - ref["sah"]) < 1e-3
-    # node transform (translation, rotation about y, uniform scale) is baked into the vertices: aiProcess_PreTransformVertices
+    # node transform (translation, rotation about y, uniform scale) is baked into the vertices: aiProcess_PreTransformVertices;
+    # the file carries no normals: aiProcess_GenSmoothNormals
     ang = np.deg2rad(30.0)
     tr = {"translation": [1.0, 2.0, -3.0], "rotation": [0.0, float(np.sin(ang / 2)), 0.0, float(np.cos(ang / 2))], "scale": [2.0, 2.0, 2.0]}
     path2 = str(tmp_path / "moved.gltf")
     w2 = pkg.scenes.save_gltf(pkg.scenes.cornell_mesh(), path2, node_transform=tr, with_normals=False)
-    out2 = json.loads(subprocess.run([exe, "--build-only", "--scene", path2], check=True, capture_output=True, text=True).stdout)
+    out2, l2 = _loaded(exe, pkg, path2, tmp_path, "moved.gmesh")
     Rm = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
     moved = (w2["verts"].astype(np.float64) * 2.0) @ Rm.T + np.array([1.0, 2.0, -3.0])
     assert np.allclose(out2["bbox"], np.concatenate([moved.min(0), moved.max(0)]), atol=1e-4)
     assert out2["triangles"] == 34
+    assert np.allclose(l2["verts"][l2["indices"]], moved[w2["indices"]], atol=1e-4)
+    want = _expected_smooth_normals(l2["verts"], l2["indices"], l2["vertex_material"])
+    assert np.allclose(l2["normals"][l2["indices"]], want, atol=2e-6)
+    assert np.allclose(np.linalg.norm(l2["normals"], axis=1), 1.0, atol=1e-5)
+
+
+def test_gltf_loader_smooths_across_seams_and_joins_duplicates(exe, pkg, tmp_path):
+    # two quads folded along a shared edge whose vertices are stored TWICE with different uv (a texture seam), no normals in the file:
+    # the generated normals on the seam are the same on both sides (same position => smoothed together, postprocess.h:169-183) and the
+    # seam vertices stay separate (their uv differ) -- while corners that carry identical data are merged even though the file lists
+    # them under different indices (aiProcess_JoinIdenticalVertices, postprocess.h:84-94)
+    base = pkg.scenes.cornell_mesh()
+    v = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0],         # quad A in z = 0
+                  [1, 0, 0], [1, 0, -1], [1, 1, -1], [1, 1, 0],       # quad B in x = 1; its first and last vertex repeat A's edge (1,0,0)-(1,1,0)
+                  [0, 0, 0], [1, 1, 0]], np.float32)                   # two exact duplicates of A's vertices 0 and 2 (same uv below)
+    uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1], [0, 0], [1, 0], [1, 1], [0, 1], [0, 0], [1, 1]], np.float32)
+    idx = np.array([[0, 1, 2], [8, 9, 3], [4, 5, 6], [4, 6, 7]], np.int32)   # triangle 1 uses the duplicates
+    mesh = dict(base); mesh.update({"verts": v, "normals": np.zeros_like(v), "uv": uv, "indices": idx, "vertex_material": np.zeros(10, np.uint32), "name": "seam"})
+    path = str(tmp_path / "seam.gltf")
+    pkg.scenes.save_gltf(mesh, path, with_normals=False)
+    out, l = _loaded(exe, pkg, path, tmp_path, "seam.gmesh")
+    assert out["triangles"] == 4 and l["verts"].shape[0] == 8           # 10 file vertices - 2 exact duplicates
+    n_corner = l["normals"][l["indices"]]; p_corner = l["verts"][l["indices"]]
+    on_seam = (p_corner[..., 0] == 1) & (p_corner[..., 2] == 0)
+    # every FACE at a position counts once with its unit normal: at (1,0,0) one z-facing and two x-facing triangles meet, at (1,1,0) two and one
+    low = on_seam & (p_corner[..., 1] == 0); high = on_seam & (p_corner[..., 1] == 1)
+    assert np.allclose(n_corner[low], np.array([2, 0, 1]) / np.sqrt(5), atol=1e-6) and np.allclose(n_corner[high], np.array([1, 0, 2]) / np.sqrt(5), atol=1e-6)
+    assert low.sum() == 3 and high.sum() == 3                           # both sides of the seam carry the same normal
+    assert np.allclose(n_corner[(p_corner[..., 0] == 0)], [0, 0, 1]) and np.allclose(n_corner[(p_corner[..., 2] == -1)], [1, 0, 0])
+    want = _expected_smooth_normals(l["verts"], l["indices"], l["vertex_material"])
+    assert np.allclose(n_corner, want, atol=2e-6)
+
+
+def test_scene_params_registry(exe, pkg, tmp_path):
+    # SceneParams::instance / loadScenes / getSceneIndex (Source/Scene.cpp:22-80): every glTF below the models directory, its .params or the defaults
+    root = tmp_path / "Models"
+    (root / "box").mkdir(parents=True); (root / "deep" / "er").mkdir(parents=True)
+    a = pkg.scenes.save_gltf(pkg.scenes.cornell_mesh(), str(root / "box" / "box.gltf"))
+    pkg.scenes.save_gltf(pkg.scenes.random_triangles_mesh(50, seed=2), str(root / "deep" / "er" / "soup.gltf"))
+    os.remove(str(root / "deep" / "er" / "soup.params"))                                    # no .params: defaults of Scene.cpp:59-61
+    (root / "box" / "notes.txt").write_text("not a scene")
+    listed = json.loads(subprocess.run([exe, "--models-root", str(root), "--list-scenes"], check=True, capture_output=True, text=True).stdout)
+    assert [s["name"] for s in listed] == ["box/box.gltf", "deep/er/soup.gltf"] and [s["index"] for s in listed] == [0, 1]
+    assert np.allclose(listed[0]["camera"], a["camera"]) and listed[0]["lights"] == a["light_count"]
+    assert listed[1]["camera"] == [1, 3, 8, 0, 270] and listed[1]["lights"] == 2
+    ok = subprocess.run([exe, "--models-root", str(root), "--build-only", "--scene", str(root / "box" / "box.gltf")], capture_output=True, text=True)
+    assert ok.returncode == 0
+    # a scene below the models directory that the registry does not list (only glTF files are scenes) is the reference's runtime_error (Scene.cpp:79)
+    pkg.scenes.save_gmesh(pkg.scenes.cornell_mesh(), str(root / "box" / "dump.gmesh"))
+    r = subprocess.run([exe, "--models-root", str(root), "--build-only", "--scene", str(root / "box" / "dump.gmesh")], capture_output=True, text=True)
+    assert r.returncode != 0 and "Non existing scene box/dump.gmesh" in r.stderr
+    # ... while the same file outside the models directory loads with its sibling .params / the defaults (an extension of this build)
+    pkg.scenes.save_gmesh(pkg.scenes.cornell_mesh(), str(tmp_path / "dump.gmesh"))
+    assert subprocess.run([exe, "--models-root", str(root), "--build-only", "--scene", str(tmp_path / "dump.gmesh")], capture_output=True, text=True).returncode == 0
 
 
 def _textured_gltf(pkg, tmp_path):
@@ -122,10 +216,28 @@ def test_missing_scene_is_a_runtime_error(exe):
     assert r.returncode != 0 and "Non existing scene" in r.stderr            # wording of Source/Scene.cpp:79, exit path of main.cpp:19-23
 
 
+def _oracle_frames(pkg, oracle, loaded, like, W, H, P, frames, textures=None):
+    """The oracle on what the C++ loader produced (mesh dump) with the camera / lights of the .params file."""
+    mesh = dict(loaded)
+    for k in ("lights", "light_count", "camera", "name"):
+        mesh[k] = like[k]
+    scene = pkg.scenes.build_scene(mesh)
+    if textures:
+        for key, arr in zip(("tex_diffuse", "tex_metallic_roughness", "tex_normal"), textures):
+            scene[key] = arr
+    orc = oracle.Renderer(scene, W, H, P, threads=8)
+    cam = oracle.Camera(W, H); cam.set_pose(*scene["camera"])
+    for _ in range(frames):
+        cam.update(); orc.set_camera(cam.buffer); orc.iterate()
+    fb = orc.framebuffer().copy()
+    orc.close()
+    return fb, scene
+
+
 @pytest.mark.gpu
-def test_cpp_renderer_equals_capi_render(exe, pkg, device, tmp_path):
-    # Renderer::update()/draw() frames through the C++ classes (scene loaded from glTF + .params) == the same frames driven
-    # through the C-ABI from Python
+def test_cpp_renderer_equals_oracle_on_the_loaded_scene(exe, pkg, oracle, device, tmp_path):
+    # Renderer::update()/draw() frames through the C++ classes (scene loaded from glTF + .params by the C++ loader, HIP kernels) against the
+    # ORACLE run on the loader's own output (gmupt_render --dump-mesh), bit for bit -- and against the same frames driven through the C-ABI
     mesh = pkg.scenes.save_gltf(pkg.scenes.random_triangles_mesh(1500, seed=4), str(tmp_path / "s12.gltf"))
     path = str(tmp_path / "s12.gltf")
     W, H, P, frames = 48, 27, 4096, 20
@@ -133,7 +245,10 @@ def test_cpp_renderer_equals_capi_render(exe, pkg, device, tmp_path):
     subprocess.run([exe, "--scene", path, "--size", "%dx%d" % (W, H), "--frames", str(frames), "--pool", str(P), "--live", str(P),
                     "--dump", dump, "--capture", "--pfm", str(tmp_path / "fb.pfm")], check=True, cwd=str(tmp_path))
     fb_cpp = np.fromfile(dump, dtype=np.float32).reshape(H, W, 4)
-    scene = pkg.scenes.build_scene(mesh)
+    _, loaded = _loaded(exe, pkg, path, tmp_path)
+    fb_orc, scene = _oracle_frames(pkg, oracle, loaded, mesh, W, H, P, frames)
+    assert np.array_equal(fb_cpp.view(np.uint32), fb_orc.view(np.uint32)), "C++ Renderer (HIP) differs from the oracle on the loader's scene"
+    assert int(fb_cpp[..., 3].view(np.uint32).sum()) > 0
     sb = pkg.capi.SceneBuffers(device, scene)
     r = pkg.capi.Renderer(device, W, H, pool_paths=P)
     r.bind_scene(sb)
@@ -153,7 +268,27 @@ def test_cpp_renderer_equals_capi_render(exe, pkg, device, tmp_path):
 
 
 @pytest.mark.gpu
-def test_cpp_renderer_with_gltf_textures_equals_capi_render(exe, pkg, device, tmp_path):
+def test_cpp_renderer_generated_normals_scene_equals_oracle(exe, pkg, oracle, tmp_path):
+    # a glTF without normals under a node transform: the loader generates the smooth normals and joins the vertices; the frames of the C++
+    # Renderer equal the oracle's on that loaded scene
+    ang = np.deg2rad(20.0)
+    tr = {"translation": [0.5, 0.0, -1.0], "rotation": [0.0, float(np.sin(ang / 2)), 0.0, float(np.cos(ang / 2))], "scale": [1.0, 1.0, 1.0]}
+    src = pkg.scenes.spheres_mesh(n_spheres=6, subdiv=2, seed=3, floor_quads=4)
+    path = str(tmp_path / "gen.gltf")
+    written = pkg.scenes.save_gltf(src, path, node_transform=tr, with_normals=False)
+    W, H, P, frames = 48, 27, 4096, 24
+    dump = str(tmp_path / "gen.f32")
+    subprocess.run([exe, "--scene", path, "--size", "%dx%d" % (W, H), "--frames", str(frames), "--pool", str(P), "--live", str(P), "--dump", dump], check=True, cwd=str(tmp_path))
+    fb_cpp = np.fromfile(dump, dtype=np.float32).reshape(H, W, 4)
+    _, loaded = _loaded(exe, pkg, path, tmp_path, "gen.gmesh")
+    assert loaded["verts"].shape[0] <= written["verts"].shape[0]
+    fb_orc, _ = _oracle_frames(pkg, oracle, loaded, written, W, H, P, frames)
+    assert np.array_equal(fb_cpp.view(np.uint32), fb_orc.view(np.uint32))
+    assert int(fb_cpp[..., 3].view(np.uint32).sum()) > 0
+
+
+@pytest.mark.gpu
+def test_cpp_renderer_with_gltf_textures_equals_oracle_and_capi_render(exe, pkg, oracle, device, tmp_path):
     # the three Texture2DArrays built by Scene::loadTextures from the glTF's PNG files drive the same pixels as the arrays
     # built from the same files through the C-ABI helpers
     path, written, arrays = _textured_gltf(pkg, tmp_path)
@@ -171,6 +306,10 @@ def test_cpp_renderer_with_gltf_textures_equals_capi_render(exe, pkg, device, tm
         cam.update(0.0); r.set_camera(cam.buffer); r.iterate()
     fb = r.framebuffer()
     assert np.array_equal(fb_cpp.view(np.uint32), fb.view(np.uint32))
+    _, loaded = _loaded(exe, pkg, path, tmp_path, "tex.gmesh")
+    loaded["materials"] = written["materials"]        # the loader assigns the layer indices while it decodes the textures (Scene.cpp:221)
+    fb_orc, _ = _oracle_frames(pkg, oracle, loaded, written, W, H, P, frames, textures=arrays)
+    assert np.array_equal(fb_cpp.view(np.uint32), fb_orc.view(np.uint32)), "C++ Renderer (HIP) differs from the oracle on the loaded textured scene"
     # and the textures matter: the same scene without them renders differently
     for key in ("tex_diffuse", "tex_metallic_roughness", "tex_normal"):
         scene[key] = None
