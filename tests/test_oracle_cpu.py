@@ -244,7 +244,7 @@ def test_tile_render_equals_full_frame_mapping(oracle, cornell_scene):
     full.close(); tile.close()
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))), ids=lambda p: os.path.basename(p)[:-4])
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*_i[0-9]*.npz"))), ids=lambda p: os.path.basename(p)[:-4])
 def test_golden_fixture(oracle, pkg, path):
     g = np.load(path)
     name = os.path.basename(path)
