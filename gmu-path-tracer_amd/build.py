@@ -24,7 +24,7 @@ FLAGS = [
 # Test-only builds of the same sources (tests/test_parity_gpu.py): the traversal ladder kept for A/B timing, and a build whose
 # two-level rank computation has one block per group (so that a small pool reaches the many-group paths of k_logic / k_material).
 TEST_BUILDS = {"variants": ["-DGMUPT_VARIANTS"], "scan1": ["-DGMUPT_SCAN_GROUP=1"]}
-EXPERIMENT_BUILDS = {"wide": ["-DGMUPT_WIDE_LINKS=1"]}   # A/B timing only (tools/), never loaded by tests
+EXPERIMENT_BUILDS = {}   # name -> extra flags of A/B timing builds (tools/ only, never loaded by tests), e.g. {"wg1024": ["-DGMUPT_DEF_BLOCK=1024", "-DGMUPT_TOP_NODES=512"]}
 
 
 def lib_path(name=None):

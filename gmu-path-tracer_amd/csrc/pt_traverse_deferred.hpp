@@ -4,9 +4,6 @@
 
 namespace gmupt {
 
-#ifndef GMUPT_WIDE_LINKS
-#define GMUPT_WIDE_LINKS 0   // 1: the last piece of a node / triangle record is fetched as 16 bytes instead of 8 (A/B knob)
-#endif
 #ifndef GMUPT_DEF_STACK
 #define GMUPT_DEF_STACK 24
 #endif
@@ -103,13 +100,7 @@ __device__ __forceinline__ void load_node_buf(__amdgpu_buffer_rsrc_t nodes, cons
         a = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off, 0, 0));
         b = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 16, 0, 0));
         c = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 32, 0, 0));
-#if GMUPT_WIDE_LINKS
-        // the link pair as a full 16-byte request: tools/micro/gather64 (profiles/r02_micro) reads 4 x 16 B per record 26 % faster than 3 x 16 + 8
-        const vec4u lk = __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 48, 0, 0);
-        d.x = (int)lk.x; d.y = (int)lk.y;
-#else
-        d = __builtin_bit_cast(vec2i, __builtin_amdgcn_raw_buffer_load_b64(nodes, off + 48, 0, 0));
-#endif
+        d = __builtin_bit_cast(vec2i, __builtin_amdgcn_raw_buffer_load_b64(nodes, off + 48, 0, 0));   // (16 bytes here instead of 8: +-0, profiles/r02_config3/bench_wide_links.json)
     }
 }
 
@@ -120,12 +111,7 @@ __device__ __forceinline__ void tri_fetch_buf(__amdgpu_buffer_rsrc_t tris, int i
     const int off = i * 48;
     r0 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(tris, off, 0, 0));
     r1 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(tris, off + 16, 0, 0));
-#if GMUPT_WIDE_LINKS
-    const vec4f w = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(tris, off + 32, 0, 0));
-    r2.x = w.x; r2.y = w.y;
-#else
     r2 = __builtin_bit_cast(vec2f, __builtin_amdgcn_raw_buffer_load_b64(tris, off + 32, 0, 0));
-#endif
 }
 
 // both slab tests of a fetched node, then the reference's choice (extensionRayCast.hlsl:132-159)
