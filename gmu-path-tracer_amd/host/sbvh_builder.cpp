@@ -41,7 +41,7 @@ namespace {
 
 constexpr int kBins = 32;                       // SplitBVHBuilder.h:40
 constexpr uint32_t kSpawnMinRefs = 2048;        // a child with fewer references stays on the worker that made it
-constexpr uint32_t kFanOutMinRefs = 1u << 19;   // nodes at least this large spread their linear passes over helper threads
+constexpr uint32_t kFanOutMinRefs = 1u << 19;   // nodes at least this large spread their linear passes over helper threads (GMUPT_BUILD_FANOUT overrides: tests)
 
 // ---------------------------------------------------------------------------------------------- boxes
 struct Box {
@@ -127,11 +127,11 @@ void forSlices(size_t n, int parts, Fn fn)
 }
 
 // ascending by key; keys are unique inside a node (a triangle occurs once per node)
-void sortKeyed(std::vector<KeyedRef>& a, int threads)
+void sortKeyed(std::vector<KeyedRef>& a, int threads, size_t parallelFrom = (size_t)1 << 16)
 {
     auto less = [](const KeyedRef& x, const KeyedRef& y) { return x.key < y.key; };
     const size_t n = a.size();
-    if (threads <= 1 || n < (1u << 16)) { std::sort(a.begin(), a.end(), less); return; }
+    if (threads <= 1 || n < parallelFrom || n < (size_t)threads * 2) { std::sort(a.begin(), a.end(), less); return; }
     int parts = 1; while (parts * 2 <= threads) parts *= 2;
     std::vector<size_t> cut((size_t)parts + 1);
     for (int p = 0; p <= parts; p++) cut[(size_t)p] = n * (size_t)p / (size_t)parts;
@@ -230,7 +230,8 @@ struct SbvhBuilder::Impl {
     uint32_t totalNodes = 0, totalRefs = 0, totalDup = 0, maxLevel = 0;
 
     float triCost(uint32_t n) const { return (float)(int)n * prm.tri_cost; }
-    int helpersFor(uint32_t n) const { return n >= kFanOutMinRefs ? threads : 1; }
+    uint32_t fanOutFrom = kFanOutMinRefs;
+    int helpersFor(uint32_t n) const { return n >= fanOutFrom ? threads : 1; }
 
     uint32_t newRef(Worker& w, const Box& b, int32_t tri)
     {
@@ -265,6 +266,7 @@ SbvhBuilder::SbvhBuilder(const float* vertices, uint32_t numVertices, const int3
     const unsigned hc = std::thread::hardware_concurrency();
     int t = env ? std::atoi(env) : (int)(hc ? (hc < 16 ? hc : 16) : 1);   // 16 = the CPU share of one GPU on the target boxes
     m->threads = t < 1 ? 1 : (t > 64 ? 64 : t);
+    if (const char* f = std::getenv("GMUPT_BUILD_FANOUT")) m->fanOutFrom = (uint32_t)std::max(2, std::atoi(f));
 }
 
 SbvhBuilder::~SbvhBuilder() = default;
@@ -314,7 +316,7 @@ void SbvhBuilder::Impl::buildAll()
         std::vector<KeyedRef> keyed(n);
         for (int a = 0; a < 3; a++) {
             forSlices(n, helpersFor(n), [&](int, size_t b, size_t e) { for (size_t i = b; i < e; i++) keyed[i] = { sortKey(refs[(uint32_t)i], a), (uint32_t)i }; });
-            sortKeyed(keyed, threads);
+            sortKeyed(keyed, threads, std::min<size_t>(fanOutFrom, (size_t)1 << 16));
             uint32_t* dst = rootTask->list(a);
             for (uint32_t i = 0; i < n; i++) dst[i] = keyed[i].ref;
         }
@@ -730,7 +732,7 @@ bool SbvhBuilder::Impl::applySpatialSplit(Task& t, const SpatialPlan& plan, Work
             for (int side = 0; side < 2; side++) {
                 std::vector<KeyedRef>& fresh = side ? newRight : newLeft;
                 for (KeyedRef& k : fresh) k.key = sortKey(refs[k.ref], a);
-                sortKeyed(fresh, sortThreads);
+                sortKeyed(fresh, sortThreads, std::min<size_t>(fanOutFrom, (size_t)1 << 16));
                 const uint32_t want = side ? MARK_RIGHT : MARK_LEFT;
                 uint32_t* dst = (side ? right : left)->list(a);
                 size_t j = 0, o = 0;

@@ -165,6 +165,27 @@ def test_builder_matches_oracle_node_for_node(pkg, oracle, name):
         assert nref > mesh["indices"].shape[0], "expected spatial splits to duplicate references"
 
 
+@pytest.mark.parametrize("threads,fanout", [(1, 1 << 30), (5, 64), (8, 1000)])
+def test_builder_thread_and_fanout_paths_give_the_same_tree(pkg, oracle, monkeypatch, threads, fanout):
+    # the builder's task pool, its helper-thread slices (sweeps, binning, partitions, merge sort) and the single-threaded path must all
+    # arrive at the oracle's tree; GMUPT_BUILD_FANOUT lowers the node size from which the slices are used so that small meshes reach them
+    monkeypatch.setenv("GMUPT_BUILD_THREADS", str(threads)); monkeypatch.setenv("GMUPT_BUILD_FANOUT", str(fanout))
+    for mesh in (pkg.scenes.random_triangles_mesh(3000, seed=5), pkg.scenes.random_triangles_mesh(700, seed=6, extent=4.0, size=3.0),
+                 pkg.scenes.spheres_mesh(n_spheres=10, subdiv=3, seed=2, floor_quads=6)):
+        built = pkg.capi.sbvh_build(mesh["verts"], mesh["indices"], mesh["vertex_material"])
+        nodes, tris, n, nref = oracle.sbvh_build(mesh["verts"], mesh["indices"], mesh["vertex_material"])
+        assert n == built["nodes"].shape[0] and nref == built["tris"].shape[0]
+        assert np.array_equal(nodes, built["nodes"].view(np.uint8)) and np.array_equal(tris, built["tris"].view(np.uint8))
+
+
+def test_builder_is_clean_under_thread_and_address_sanitizers():
+    # CPU build of the builder under -fsanitize=thread and -fsanitize=address,undefined (task pool + helper-thread slices forced on small
+    # nodes, a soup that duplicates 2 references per triangle): tools/sanitize/run.sh
+    import subprocess
+    r = subprocess.run([os.path.join(ROOT, "tools", "sanitize", "run.sh")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "sanitizers: clean" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_builder_matches_oracle_on_random_small_meshes(pkg, oracle):
     # property test of the same node-for-node agreement on adversarial little meshes: coordinates on a coarse grid (many exact
     # ties in the sort keys, coplanar and degenerate triangles, duplicated triangles, zero-extent boxes)
