@@ -413,9 +413,11 @@ static int build_traversal_copy(gmupt_renderer* r, const gmupt_buffer* nodesB, c
         }
         numInner = nextIdx;   // records of the packed array (one may be an unused filler)
     }
-    for (size_t i = 0; i < R; i++)
+    for (size_t i = 0; i < R; i++) {
         for (int k = 0; k < 3; k++)
             if (tris[i].v[k] < 0 || (size_t)tris[i].v[k] >= V) return fail(GMUPT_ERR_INVALID_ARGUMENT, "bind_scene: triangle record %zu references vertex %d of %zu", i, tris[i].v[k], V);
+        if (tris[i].materialID >= (uint32_t)GMUPT_MAX_LIGHTS) return fail(GMUPT_ERR_INVALID_ARGUMENT, "bind_scene: triangle record %zu has material %u (the material table holds %d entries, logic.hlsl:8)", i, tris[i].materialID, GMUPT_MAX_LIGHTS);
+    }
 
     auto desc = [&](int32_t child) -> int32_t {
         const gmupt_bvh_node& c = nodes[(size_t)child];

@@ -31,12 +31,21 @@ MeshData MeshData::load(const std::string& path)
 		throw std::runtime_error("Not a gmesh file: " + path);
 	MeshData m;
 	const size_t nv = hdr[0], nt = hdr[1], nm = hdr[2], hasUV = hdr[3];
+	{ // the header must fit the file (a corrupt count must not become a multi-gigabyte allocation)
+		const long at = std::ftell(file.f); std::fseek(file.f, 0, SEEK_END); const long end = std::ftell(file.f); std::fseek(file.f, at, SEEK_SET);
+		const unsigned long long need = 4ull * (nv * 3 + nv * 3 + (hasUV ? nv * 2 : 0) + nv + nt * 3) + sizeof(gmupt_material) * (unsigned long long)nm;
+		if (at < 0 || end < at || need > (unsigned long long)(end - at)) throw std::runtime_error("Truncated mesh file " + path);
+	}
 	readVec(file.f, m.vertices, nv * 3, path);
 	readVec(file.f, m.normals, nv * 3, path);
 	if (hasUV) readVec(file.f, m.texCoords, nv * 2, path);
 	readVec(file.f, m.vertexMaterial, nv, path);
 	readVec(file.f, m.indices, nt * 3, path);
 	readVec(file.f, m.materials, nm, path);
+	// a dump is input like any other file: nothing in it may index outside its own arrays
+	for (int32_t v : m.indices) if (v < 0 || static_cast<size_t>(v) >= nv) throw std::runtime_error("Corrupt mesh file (vertex index out of range): " + path);
+	for (uint32_t mat : m.vertexMaterial) if (mat >= (nm ? nm : 1)) throw std::runtime_error("Corrupt mesh file (material index out of range): " + path);
+	if (nm == 0) throw std::runtime_error("Corrupt mesh file (no materials): " + path);
 	return m;
 }
 

@@ -186,6 +186,14 @@ def test_builder_is_clean_under_thread_and_address_sanitizers():
     assert r.returncode == 0 and "sanitizers: clean" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+def test_scene_loaders_survive_mutated_files_under_sanitizers():
+    # glTF / GLB / PNG / .gmesh / .params readers compiled with -fsanitize=address,undefined and fed mutated files: every mutant is loaded
+    # or rejected with an exception (tools/sanitize/fuzz_loader.py; a longer run: python tools/sanitize/fuzz_loader.py 300)
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sanitize", "fuzz_loader.py"), "10"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "no crash, no sanitizer report" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def test_builder_matches_oracle_on_random_small_meshes(pkg, oracle):
     # property test of the same node-for-node agreement on adversarial little meshes: coordinates on a coarse grid (many exact
     # ties in the sort keys, coplanar and degenerate triangles, duplicated triangles, zero-extent boxes)
