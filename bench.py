@@ -40,10 +40,27 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s tuned float4 copy; 4.6-4.8 TB/s plain grid-stride copy on this pool, profiles/r02_micro/hbm_copy.txt)
-# Ceiling of the access pattern that bounds the ray cast: random 64-byte records gathered by one lane each (4 x 16-byte requests per record),
-# 32 waves per CU, dependent chains -- tools/micro/gather64.hip shape A, table of the size of the config-3 BVH (25.6 MB: served by L2 + Infinity
-# Cache).  Measured on this pool: profiles/r02_micro/gather64_25MB.txt.  The quad-cooperative shapes (B, E) are SLOWER than A on gfx950.
-GATHER_PEAK_GRECS = {"cache_resident_25MB": 105.2, "hbm_resident_1GB": 57.1}
+# Ceilings of the access pattern that bounds the ray cast: random records gathered by one lane each, 32 waves per CU, dependent chains
+# (tools/micro/gather64.hip, measured on this pool: profiles/r02_micro/).  Shape A = 64-byte records as 4 x 16-byte requests (a node),
+# shape D = 48-byte records as 3 x 16-byte requests (a triangle); G records/s by table size in MB.  The quad-cooperative shapes (B, E)
+# are SLOWER than A on gfx950 and lanes asking for the SAME record (C) are merged -- neither applies to incoherent rays.
+GATHER_TABLE_MB = [2.1, 4.2, 8.4, 16.8, 25.6, 1024.0]
+GATHER_A_GRECS = [157.4, 153.1, 135.5, 119.3, 105.2, 57.1]
+GATHER_D_GRECS = [202.1, 202.4, 192.0, 166.8, 127.6, 45.7]
+
+
+def gather_ceiling(node_recs, tri_recs, table_mb=None):
+    """G records/s of a launch that gathers this mix of node and triangle records at the micro-benchmark's rates: every record an L2 hit
+    (table_mb None: the smallest table) or a uniformly random table of table_mb (log-interpolated between the measured sizes)."""
+    import math
+    if table_mb is None:
+        a, d = GATHER_A_GRECS[0], GATHER_D_GRECS[0]
+    else:
+        x = min(max(table_mb, GATHER_TABLE_MB[0]), GATHER_TABLE_MB[-1])
+        k = max(i for i in range(len(GATHER_TABLE_MB) - 1) if GATHER_TABLE_MB[i] <= x)
+        t = math.log(x / GATHER_TABLE_MB[k]) / math.log(GATHER_TABLE_MB[k + 1] / GATHER_TABLE_MB[k])
+        a = GATHER_A_GRECS[k] + t * (GATHER_A_GRECS[k + 1] - GATHER_A_GRECS[k]); d = GATHER_D_GRECS[k] + t * (GATHER_D_GRECS[k + 1] - GATHER_D_GRECS[k])
+    return (node_recs + tri_recs) / (node_recs / a + tri_recs / d)
 
 
 def parse_args():
@@ -88,17 +105,19 @@ def self_launch(args):
     return 0
 
 
-def roofline_object(capi, s2, steps, cast_ms, scene, table_key):
+def roofline_object(capi, s2, steps, cast_ms, scene, table_mb):
     """Roofline of the ray-cast launch from the counting replay (s2) and the HIP-event launch time of the timed region.
 
-    The kernel is NOT bound by HBM on the config-3 scene: its 25 MB of traversal records live in L2 / Infinity Cache.  What bounds it is
-    the rate at which the chip gathers random 64-byte records (tools/micro/gather64.hip), so that is the roof:
+    The kernel is NOT bound by HBM on the config-3 scene: its 19 MB of traversal records live in L2 / Infinity Cache.  What bounds it is
+    the rate at which the chip gathers random records (tools/micro/gather64.hip), so that is the roof:
       achieved = (64-byte node records + 48-byte triangle records fetched from global memory per launch) / launch time
-      peak     = gather64 shape A on a table of this size (GATHER_PEAK_GRECS; output kept in profiles/r02_micro/)
+      peak     = the same mix of records gathered at the micro-benchmark's rate when EVERY record is an L2 hit (2 MB table): no cache
+                 behaviour of this per-lane access shape can beat it; `uniform_table` is the rate for a uniformly random table of the
+                 size of this scene's traversal records (the walk is not uniform -- the top of the tree is hot -- so a launch may exceed it)
     Node visits served by the LDS-resident tree top issue no vector-memory request and are not counted.  The HBM view is a secondary
     object: `kernel_bytes` are the bytes the kernel's own algorithm moves (64 B per global node visit, 48 B per triangle test, ray in /
     result out), shown against the 8 TB/s HBM peak for orientation only -- most of them are cache hits; measured memory-side traffic
-    (rocprofv3 FETCH_SIZE / WRITE_SIZE) comes from a profiler run, never from this process: `traffic` is null here and the directory
+    (rocprofv3 request counters) comes from a profiler run, never from this process: `traffic` is null here and the directory
     of the matching profile is named instead.  `reference_equivalent_bytes` is SURVEY 8(d)'s formula (what the reference's kernels would
     read for the same walks: 144 B per inner step, 52 B per triangle test); it is not a fraction of anything.
     """
@@ -111,7 +130,8 @@ def roofline_object(capi, s2, steps, cast_ms, scene, table_key):
     recs = node_recs + tri_recs
     sec = cast_ms * 1e-3
     achieved = recs / sec / 1e9 if sec > 0 else 0.0
-    peak = GATHER_PEAK_GRECS[table_key]
+    peak = gather_ceiling(node_recs, tri_recs)
+    uniform = gather_ceiling(node_recs, tri_recs, table_mb)
     ray_io = (s2.ext_rays * (4 + 24 + 48) + (s2.sh_rays * (4 + 28 + 4) if fused else 0)) / k
     kernel_bytes = node_recs * 64 + tri_recs * 48 + ray_io
     ref_bytes = (s2.ext_rays * (4 + 24 + 48 + 32 * scene["light_count"] + 48) + 96 * s2.ext_inner + 52 * s2.ext_tris) / k
@@ -119,8 +139,9 @@ def roofline_object(capi, s2, steps, cast_ms, scene, table_key):
         ref_bytes += (s2.sh_rays * (4 + 24 + 4 + 48 + 4) + 96 * s2.sh_inner + 52 * s2.sh_tris) / k
     kname = "k_cast_f" if (s2.flags & capi.STAT_CAST_FETCH) else ("fused ray cast (variant)" if fused else "k_extend_d")
     return {"bound": "gather (random 64-byte records; vector-memory request rate)", "kernel": kname,
-            "achieved": round(achieved, 2), "peak": peak, "unit": "Grecords/s", "frac": round(achieved / peak, 4), "traffic": None,
-            "peak_source": "tools/micro/gather64.hip shape A, %s table: profiles/r02_micro/" % table_key,
+            "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "Grecords/s", "frac": round(achieved / peak, 4), "traffic": None,
+            "peak_source": "tools/micro/gather64.hip shapes A (nodes) and D (triangles), L2-resident table, weighted by this launch's record mix: profiles/r02_micro/",
+            "uniform_table": {"table_mb": round(table_mb, 1), "grecords_per_s": round(uniform, 1), "frac": round(achieved / uniform, 4)},
             "avg_launch_ms": round(cast_ms, 4), "records_per_launch": int(recs), "node_records_per_launch": int(node_recs), "triangle_records_per_launch": int(tri_recs),
             "lds_top_share_of_node_visits": round(top / max(inner, 1), 4),
             "rays_per_launch": (s2.ext_rays + (s2.sh_rays if fused else 0)) / k, "shadow_rays_per_launch": s2.sh_rays / k,
@@ -244,7 +265,9 @@ def main_rank(args):
         step(r2, cam2, args.steps)
         s2 = r2.stats()
         r2.close()
-        roofline = roofline_object(capi, s2, args.steps, cast_ms, scene, "cache_resident_25MB")
+        n_inner = int((scene["nodes"]["isLeaf"] == 0).sum())
+        table_mb = (n_inner * 64 + (int(scene["tris"].shape[0]) + 1) * 48) / 1e6      # the traversal copy: Node64 + Tri48 records
+        roofline = roofline_object(capi, s2, args.steps, cast_ms, scene, table_mb)
 
     # ------------------------------------------------------------------ the whole job: W*H*spp paths, feed + drain (each rank its band)
     full_frame = None
