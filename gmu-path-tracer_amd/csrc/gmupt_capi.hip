@@ -692,7 +692,7 @@ extern "C" int gmupt_get_stats(gmupt_renderer* r, gmupt_stats* out)
     for (int k = 0; k < 4; k++) out->lane_census[k] = ds.laneCensus[k];
     out->cast_waves = ds.castWaves; out->cast_wave_ticks = ds.castWaveClocks; out->cast_wave_ticks_max = ds.castWaveClocksMax;
     out->cast_drain_ticks = ds.castDrainClocks; out->cast_drain_iters = ds.castDrainIters; out->cast_drain_busy_lanes = ds.castDrainBusyLanes;
-    out->ext_top_inner = ds.extTopInner; out->sh_top_inner = ds.shTopInner;
+    out->ext_top_inner = ds.extTopInner; out->sh_top_inner = ds.shTopInner; out->cast_helper_subtrees = ds.castHelperSubtrees;
     out->ext_wave_inner = ds.extWaveInner; out->ext_wave_tris = ds.extWaveTris; out->sh_wave_inner = ds.shWaveInner; out->sh_wave_tris = ds.shWaveTris;
     return GMUPT_OK;
 }

@@ -60,6 +60,7 @@ struct DevStats {
     unsigned long long castWaveEndHist[32]; // wave lifetimes in 50-us buckets (all waves of the persistent grid start together)
     unsigned long long rayInnerHist[32];    // extension rays by inner nodes visited, 16 per bucket
     unsigned long long extTopInner, shTopInner; // inner-node visits served by the LDS-resident top of the tree (no vector-memory request)
+    unsigned long long castHelperSubtrees;      // subtrees handed to idle lanes in the drain of the fused ray cast
     uint32_t activePaths;
     uint32_t stackOverflow; // traversal needed more than the provisioned stack (results then differ from an unbounded stack)
 };

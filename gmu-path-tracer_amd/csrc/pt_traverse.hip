@@ -246,9 +246,12 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_f(RenderParams p)
     uint32_t next = 0, end = 0;
     uint32_t chunkBase = 0, qe0 = kQueueHole, qe1 = kQueueHole;  // the current chunk of queue entries, lane l holds entries l and 64 + l
     int phase = 0;
-    const unsigned long long tStart = STATS ? wall_clock64() : 0ull;
+#ifndef GMUPT_DRAIN_TIMING
+#define GMUPT_DRAIN_TIMING 0   // 1 (diagnostic build only): the plain kernel stamps its start, the moment a wave finds both queues empty, and its exit
+#endif
+    const unsigned long long tStart = (STATS || GMUPT_DRAIN_TIMING) ? wall_clock64() : 0ull;
     unsigned long long tDrain = 0ull; uint32_t drainIters = 0, drainBusy = 0;
-    uint32_t rayInner = 0, census0 = 0, census1 = 0, census2 = 0, census3 = 0, topE = 0, topS = 0;
+    uint32_t rayInner = 0, census0 = 0, census1 = 0, census2 = 0, census3 = 0, topE = 0, topS = 0, helped = 0;
 
     bool haveRay = false;
     int kind = 0;                 // 0: extension ray, 1: shadow ray
@@ -260,8 +263,79 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_f(RenderParams p)
     int cur = kDone;
     uint32_t qHead = 0, qCount = 0;
     int ti = -1;
+    // ---- the drain (both queues exhausted): a wave is as slow as its longest ray, so the lanes that have finished HELP the ones still
+    // walking.  Boxes are never pruned, so a deferred subtree can be walked by another lane; the BOTTOM entry of a ray's stack is the
+    // subtree the ray would visit last, hence its hits only count if they are strictly closer than everything the owner finds itself
+    // (ties go to the earlier test, extensionRayCast.hlsl:64) -- and among helpers the later donated subtree is visited earlier.
+    int owner = -1;               // >= 0: this lane walks a subtree donated by lane `owner` (same ray, own stack, own leaf FIFO)
+    uint32_t bottom = 1;          // lowest live entry of this lane's stack (entries below it were donated; the slot under it holds the sentinel)
+    uint32_t outstanding = 0;     // owner: helpers that have not reported yet
+    uint32_t donations = 0;       // owner: subtrees donated so far; helper: the number of its donation
+    float tT = kFltMax, uT = 0.0f, vT = 0.0f; int refT = -1; uint32_t dT = 0;   // owner: best helper result so far (by t, then by LATER donation)
+    const uint32_t lane = threadIdx.x & 63u;
 
     for (;;) {
+        if (phase == 2) { // wave-uniform: drain service
+            // (a) helpers that have finished their subtree report to their owner
+            unsigned long long fin = __ballot(haveRay && owner >= 0 && cur == kDone && qCount == 0 && ti < 0);
+            while (fin) {
+                const int hl = __builtin_ctzll(fin); fin &= fin - 1ull;
+                const int ol = __builtin_amdgcn_readlane(owner, hl);
+                const float th = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, distance), hl));
+                const float uh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hu), hl));
+                const float vh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hv), hl));
+                const int rh = __builtin_amdgcn_readlane(hitRef, hl);
+                const uint32_t dh = (uint32_t)__builtin_amdgcn_readlane((int)donations, hl);
+                if ((int)lane == ol) {
+                    outstanding--;
+                    if (rh >= 0) {
+                        if (kind == 1) refT = rh;                                                       // any occluder decides a shadow ray
+                        else if (th < tT || (th == tT && dh > dT)) { tT = th; uT = uh; vT = vh; refT = rh; dT = dh; }
+                    }
+                }
+                if ((int)lane == hl) { haveRay = false; owner = -1; }
+            }
+            // (b) owners that are done and have heard from all their helpers are written back now: their lanes become free
+            const bool done = haveRay && owner < 0 && outstanding == 0u && cur == kDone && qCount == 0 && ti < 0;
+            const unsigned long long wantHelp = __ballot(haveRay && owner < 0 && stk.ptr > bottom && bottom + 1u < (uint32_t)kDefStack && donations < 12u);
+            if (wantHelp != 0ull && done) {
+                if (kind == 0) {
+                    if (refT >= 0 && tT < distance) { distance = tT; hu = uT; hv = vT; hitRef = refT; }
+                    finish_extension_ray(p, index, o, d, distance, hu, hv, hitRef);
+                } else stu(p, F_IN_SHADOW, index, (hitRef >= 0 || refT >= 0) ? 1u : 0u);
+                haveRay = false; tT = kFltMax; refT = -1; dT = 0;
+            }
+            // (c) free lanes take the bottom stack entry of lanes that still have deferred subtrees
+#ifndef GMUPT_HELP_PAIRS
+#define GMUPT_HELP_PAIRS 2   // hand-overs per loop iteration and wave (each costs ~60 wave instructions; 0 / 1 / 2 / 4: 1.032 / - / 1.010 / 1.020 ms per launch)
+#endif
+            unsigned long long donors = wantHelp, freeLanes = __ballot(!haveRay);
+            for (int pair = 0; pair < GMUPT_HELP_PAIRS && donors != 0ull && freeLanes != 0ull; pair++) {
+                const int dl = __builtin_ctzll(donors); donors &= donors - 1ull;
+                const int fl = __builtin_ctzll(freeLanes); freeLanes &= freeLanes - 1ull;
+                int node = 0;
+                if ((int)lane == dl) {
+                    int* slot = s_stack + bottom * kDefBlock + threadIdx.x;
+                    node = *slot; *slot = kDone;           // the slot becomes the sentinel of what is left of the owner's stack
+                    bottom++; outstanding++; donations++;
+                    if (STATS) helped++;
+                }
+                node = __builtin_amdgcn_readlane(node, dl);
+                const int k2 = __builtin_amdgcn_readlane(kind, dl);
+                const uint32_t i2 = (uint32_t)__builtin_amdgcn_readlane((int)index, dl), n2 = (uint32_t)__builtin_amdgcn_readlane((int)donations, dl);
+                const float ox = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o.x), dl)), oy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o.y), dl)), oz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o.z), dl));
+                const float dx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d.x), dl)), dy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d.y), dl)), dz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d.z), dl));
+                const float lim = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, distance), dl));
+                if ((int)lane == fl) {
+                    haveRay = true; owner = dl; kind = k2; index = i2; donations = n2;
+                    o = mk3(ox, oy, oz); d = mk3(dx, dy, dz); invdir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    distance = k2 == 1 ? lim : kFltMax;     // shadow: the distance of the light; extension: no hit yet
+                    hitRef = -1; hu = 0.0f; hv = 0.0f;
+                    stk.reset(); bottom = 1; outstanding = 0; qHead = 0; qCount = 0; ti = -1;
+                    cur = node;
+                }
+            }
+        }
         const bool idle = (cur == kDone) && (qCount == 0) && (ti < 0);
         const unsigned long long idleMask = __ballot(idle);
         const int nIdle = __popcll(idleMask);
@@ -277,7 +351,6 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_f(RenderParams p)
                     // its entry from a neighbour's register instead of starting with a dependent queue read
                     chunkBase = base;
                     const uint32_t* q = phase == 0 ? qExt : qSh;
-                    const uint32_t lane = threadIdx.x & 63u;
                     qe0 = (base + lane < end) ? q[base + lane] : kQueueHole;
                     qe1 = (base + 64u + lane < end) ? q[base + 64u + lane] : kQueueHole;
                 }
@@ -305,14 +378,16 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_f(RenderParams p)
                 if (haveRay) {
                     if (STATS && kind == 0) { atomicAdd(&p.stats->rayInnerHist[rayInner / 16u < 31u ? rayInner / 16u : 31u], 1ull); rayInner = 0; }
                     if (kind == 0) {
-                        // finish the extension ray: extensionRayCast.hlsl:218-232
+                        // finish the extension ray: extensionRayCast.hlsl:218-232 (a helper's hit only counts if it is strictly closer)
+                        if (refT >= 0 && tT < distance) { distance = tT; hu = uT; hv = vT; hitRef = refT; }
                         finish_extension_ray(p, index, o, d, distance, hu, hv, hitRef);
                     } else {
-                        stu(p, F_IN_SHADOW, index, hitRef >= 0 ? 1u : 0u);   // shadowRayCast.hlsl:167
+                        stu(p, F_IN_SHADOW, index, (hitRef >= 0 || refT >= 0) ? 1u : 0u);   // shadowRayCast.hlsl:167
                     }
-                    haveRay = false;
+                    haveRay = false; tT = kFltMax; refT = -1; dT = 0;
                 }
                 if (newRay) {
+                    bottom = 1; donations = 0;
                     haveRay = true; kind = phase; index = newIndex;            // phase is 0 (extension) or 1 (shadow) here
                     if (STATS) { if (phase == 0) raysE++; else raysS++; }
                     o = newO; d = newD; distance = newDist;
@@ -326,6 +401,7 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_f(RenderParams p)
             next = (next + (uint32_t)nIdle < end) ? next + (uint32_t)nIdle : end;
         }
 
+        if (GMUPT_DRAIN_TIMING && !STATS && phase == 2) { if (tDrain == 0ull) tDrain = wall_clock64(); drainIters++; }
         if (STATS) { // lane census: where do the 64 lanes of a wave spend the loop iterations?
             const bool pendingNow = (qCount > 0) || (ti >= 0);
             if (phase == 2) { if (tDrain == 0ull) tDrain = wall_clock64(); drainIters++; drainBusy += __popcll(__ballot(haveRay && !(cur == kDone && !pendingNow))); }
@@ -376,9 +452,14 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_f(RenderParams p)
             }
         }
     }
+    if (GMUPT_DRAIN_TIMING && !STATS && (threadIdx.x & 63) == 0) {
+        const unsigned long long tEnd = wall_clock64();
+        atomicAdd(&p.stats->castDrainClocks, tDrain ? tEnd - tDrain : 0ull); atomicAdd(&p.stats->castDrainIters, (unsigned long long)drainIters);
+        atomicAdd(&p.stats->castWaves, 1ull); atomicAdd(&p.stats->castWaveClocks, tEnd - tStart); atomicMax(&p.stats->castWaveClocksMax, tEnd - tStart);
+    }
     if (STATS) { flush_counts(p.stats, tcE, raysE, true); flush_wave_iters(p.stats, wInE, wTrE, true);
                  flush_counts(p.stats, tcS, raysS, false); flush_wave_iters(p.stats, wInS, wTrS, false);
-                 flush_sum(&p.stats->extTopInner, topE); flush_sum(&p.stats->shTopInner, topS);
+                 flush_sum(&p.stats->extTopInner, topE); flush_sum(&p.stats->shTopInner, topS); flush_sum(&p.stats->castHelperSubtrees, helped);
                  if ((threadIdx.x & 63) == 0) {
                      const unsigned long long tEnd = wall_clock64();
                      const unsigned long long life = tEnd - tStart;

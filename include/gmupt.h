@@ -182,6 +182,7 @@ typedef struct {
     uint64_t cast_wave_end_hist[32];  /* wave lifetimes in 50-us buckets */
     uint64_t ray_inner_hist[32];      /* extension rays by inner nodes visited, 16 per bucket */
     uint64_t ext_top_inner, sh_top_inner; /* inner-node visits served by the LDS-resident top of the tree (k_cast_f, collect_stats) */
+    uint64_t cast_helper_subtrees;        /* deferred subtrees walked by a finished lane for a lane still walking, in the drain of k_cast_f (collect_stats) */
 } gmupt_stats;
 int gmupt_get_stats(gmupt_renderer* r, gmupt_stats* out); /* synchronises */
 int gmupt_reset_stats(gmupt_renderer* r);

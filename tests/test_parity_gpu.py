@@ -207,6 +207,8 @@ def test_traversal_statistics_match(pkg, device, soup_scene):
     # the any-hit shadow ray is free in how far it walks (deferred triangle tests walk further, skipping boxes entered beyond the
     # light walks less): only the number of rays and -- through _assert_same above -- every inShadow bit must agree
     assert so.shRays == sh.sh_rays and sh.sh_inner > 0 and sh.sh_tris > 0
+    # in the drain of every launch finished lanes walk deferred subtrees of the lanes still busy: it happened, and (above) nothing changed
+    assert sh.cast_helper_subtrees > 0
     hip.close(); sb.close(); orc.close()
 
 
