@@ -243,7 +243,7 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_f(RenderParams p)
     const uint32_t* qSh = p.queues + (size_t)Q_SHADOW_RAY * p.P;
     const __amdgpu_buffer_rsrc_t rNodes = make_rsrc(ts.nodes, ts.triBase * 64u);              // ts.triBase = number of packed nodes
     const __amdgpu_buffer_rsrc_t rTris = make_rsrc(ts.tris, (p.scene.numTris + 1u) * 48u);    // + the sentinel record
-    uint32_t next = 0, end = 0;
+    uint32_t next = 0, end = 0, lastBase = 0;
     uint32_t chunkBase = 0, qe0 = kQueueHole, qe1 = kQueueHole;  // the current chunk of queue entries, lane l holds entries l and 64 + l
     int phase = 0;
 #ifndef GMUPT_DRAIN_TIMING
@@ -305,34 +305,36 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_f(RenderParams p)
                 } else stu(p, F_IN_SHADOW, index, (hitRef >= 0 || refT >= 0) ? 1u : 0u);
                 haveRay = false; tT = kFltMax; refT = -1; dT = 0;
             }
-            // (c) free lanes take the bottom stack entry of lanes that still have deferred subtrees
-#ifndef GMUPT_HELP_PAIRS
-#define GMUPT_HELP_PAIRS 2   // hand-overs per loop iteration and wave (each costs ~60 wave instructions; 0 / 1 / 2 / 4: 1.032 / - / 1.010 / 1.020 ms per launch)
-#endif
-            unsigned long long donors = wantHelp, freeLanes = __ballot(!haveRay);
-            for (int pair = 0; pair < GMUPT_HELP_PAIRS && donors != 0ull && freeLanes != 0ull; pair++) {
-                const int dl = __builtin_ctzll(donors); donors &= donors - 1ull;
-                const int fl = __builtin_ctzll(freeLanes); freeLanes &= freeLanes - 1ull;
+            // (c) free lanes take the bottom stack entry of lanes that still have deferred subtrees: the k-th free lane pairs with the k-th
+            //     donor, all pairs of the wave at once (the donors post their lane number to lane k, the takers fetch the ray from there)
+            const unsigned long long freeLanes = __ballot(!haveRay);
+            if (wantHelp != 0ull && freeLanes != 0ull) {
+                const uint32_t nDonors = (uint32_t)__popcll(wantHelp), nFree = (uint32_t)__popcll(freeLanes);
+                const uint32_t nPairs = nDonors < nFree ? nDonors : nFree;
+                const bool isDonor = ((wantHelp >> lane) & 1ull) != 0ull;
+                const uint32_t dRank = prefix_rank(wantHelp), fRank = prefix_rank(freeLanes);
+                const bool gives = isDonor && dRank < nPairs, takes = !haveRay && fRank < nPairs;
                 int node = 0;
-                if ((int)lane == dl) {
+                if (gives) {
                     int* slot = s_stack + bottom * kDefBlock + threadIdx.x;
                     node = *slot; *slot = kDone;           // the slot becomes the sentinel of what is left of the owner's stack
                     bottom++; outstanding++; donations++;
                     if (STATS) helped++;
                 }
-                node = __builtin_amdgcn_readlane(node, dl);
-                const int k2 = __builtin_amdgcn_readlane(kind, dl);
-                const uint32_t i2 = (uint32_t)__builtin_amdgcn_readlane((int)index, dl), n2 = (uint32_t)__builtin_amdgcn_readlane((int)donations, dl);
-                const float ox = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o.x), dl)), oy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o.y), dl)), oz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o.z), dl));
-                const float dx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d.x), dl)), dy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d.y), dl)), dz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d.z), dl));
-                const float lim = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, distance), dl));
-                if ((int)lane == fl) {
-                    haveRay = true; owner = dl; kind = k2; index = i2; donations = n2;
+                // lane k learns which lane the k-th donor is; a taker with rank k reads that number from lane k, then the ray from the donor
+                const int donorOfRank = __builtin_amdgcn_ds_permute((int)((gives ? dRank : 63u) << 2), gives ? (int)lane : 0);
+                const int src = __shfl(donorOfRank, takes ? (int)fRank : 0);
+                const int sl = takes ? src : (int)lane;
+                const int node2 = __shfl(node, sl), k2 = __shfl(kind, sl), i2 = __shfl((int)index, sl), n2 = __shfl((int)donations, sl);
+                const float ox = __shfl(o.x, sl), oy = __shfl(o.y, sl), oz = __shfl(o.z, sl), dx = __shfl(d.x, sl), dy = __shfl(d.y, sl), dz = __shfl(d.z, sl);
+                const float lim = __shfl(distance, sl);
+                if (takes) {
+                    haveRay = true; owner = src; kind = k2; index = (uint32_t)i2; donations = (uint32_t)n2;
                     o = mk3(ox, oy, oz); d = mk3(dx, dy, dz); invdir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                     distance = k2 == 1 ? lim : kFltMax;     // shadow: the distance of the light; extension: no hit yet
                     hitRef = -1; hu = 0.0f; hv = 0.0f;
                     stk.reset(); bottom = 1; outstanding = 0; qHead = 0; qCount = 0; ti = -1;
-                    cur = node;
+                    cur = node2;
                 }
             }
         }
@@ -342,11 +344,20 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_f(RenderParams p)
         if (nIdle == 64 || (nIdle >= (int)p.tuneRefill && phase < 2)) { // wave-uniform
             while (next >= end && phase < 2) { // next chunk of the current queue, or the first one of the next queue
                 uint32_t base = 0;
-                if ((threadIdx.x & 63) == 0) base = atomicAdd(&p.travCounters[phase], p.raysPerWave);
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                 const uint32_t count = phase == 0 ? countExt : countSh;
+                // towards the end of the LAST queue the chunks shrink: the waves then run dry within half the time of each other
+                // (the position is estimated from this wave's previous chunk: every other wave has taken about one since)
+                const uint32_t gridWaves = gridDim.x * (uint32_t)(kDefBlock / 64);
+#ifndef GMUPT_TAIL_CHUNKS
+#define GMUPT_TAIL_CHUNKS 2
+#endif
+                const bool tail = GMUPT_TAIL_CHUNKS && phase == 1 && lastBase + (uint32_t)GMUPT_TAIL_CHUNKS * gridWaves * p.raysPerWave > count;
+                const uint32_t req = tail ? (p.raysPerWave > 64u ? p.raysPerWave / 2u : p.raysPerWave) : p.raysPerWave;
+                if ((threadIdx.x & 63) == 0) base = atomicAdd(&p.travCounters[phase], req);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                 if (base < count) {
-                    next = base; end = (base + p.raysPerWave < count) ? base + p.raysPerWave : count;
+                    lastBase = base;
+                    next = base; end = (base + req < count) ? base + req : count;
                     // the whole chunk of queue entries goes into two registers per lane (two coalesced loads): a refill then takes
                     // its entry from a neighbour's register instead of starting with a dependent queue read
                     chunkBase = base;
@@ -354,7 +365,7 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_f(RenderParams p)
                     qe0 = (base + lane < end) ? q[base + lane] : kQueueHole;
                     qe1 = (base + 64u + lane < end) ? q[base + 64u + lane] : kQueueHole;
                 }
-                else { phase++; next = end = 0; }
+                else { phase++; next = end = 0; lastBase = 0; }
             }
 #ifndef GMUPT_KNOCKOUT
 #define GMUPT_KNOCKOUT 0   // timing experiments only (tools/knockout.py; results are wrong): 1 no result stores, 3 no triangle tests
@@ -456,6 +467,8 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_f(RenderParams p)
         const unsigned long long tEnd = wall_clock64();
         atomicAdd(&p.stats->castDrainClocks, tDrain ? tEnd - tDrain : 0ull); atomicAdd(&p.stats->castDrainIters, (unsigned long long)drainIters);
         atomicAdd(&p.stats->castWaves, 1ull); atomicAdd(&p.stats->castWaveClocks, tEnd - tStart); atomicMax(&p.stats->castWaveClocksMax, tEnd - tStart);
+        const unsigned long long life = tEnd - tStart, bucket = life / 4000ull;    // 40-us buckets of the wave lifetimes (all waves start together)
+        atomicAdd(&p.stats->castWaveEndHist[bucket < 31ull ? bucket : 31ull], 1ull);
     }
     if (STATS) { flush_counts(p.stats, tcE, raysE, true); flush_wave_iters(p.stats, wInE, wTrE, true);
                  flush_counts(p.stats, tcS, raysS, false); flush_wave_iters(p.stats, wInS, wTrS, false);

@@ -18,3 +18,6 @@ waves = st.cast_waves / N
 print("pool %d: launch %.4f ms (HIP events); per wave: lifetime %.1f us (max %.1f), drain %.1f us = %.1f %% of the lifetime, %.1f loop iterations in the drain; waves %d"
       % (pool, st.ms_extend / st.timed_iterations, st.cast_wave_ticks / st.cast_waves / 100.0, st.cast_wave_ticks_max / 100.0, st.cast_drain_ticks / st.cast_waves / 100.0,
          100.0 * st.cast_drain_ticks / st.cast_wave_ticks, st.cast_drain_iters / st.cast_waves, waves))
+import numpy as np
+h = np.array(list(st.cast_wave_end_hist), dtype=np.float64) / N
+print("wave lifetimes, 40-us buckets (waves per launch):", h.round(0).astype(int).tolist())
