@@ -227,8 +227,13 @@ __global__ __launch_bounds__(kDefBlock) void k_shadow_d(RenderParams p)
 // fetch of the walking lanes AND the triangle fetch of the lanes with a pending leaf, then does the slab tests and the triangle test.
 // A burst therefore costs no memory round trips of its own (REPS per loop iteration instead of REPS + BURST); what is tested, and in which
 // order per ray, is unchanged: leaves leave the per-lane FIFO in visit order.  BURST is unused here (one triangle record per step).
+#ifdef GMUPT_CAST_WAVES_PER_EU
+#define GMUPT_CAST_OCCUPANCY __attribute__((amdgpu_waves_per_eu(GMUPT_CAST_WAVES_PER_EU, GMUPT_CAST_WAVES_PER_EU)))
+#else
+#define GMUPT_CAST_OCCUPANCY
+#endif
 template <bool STATS, bool OVF, bool TOP, int REPS, int BURST>
-__global__ __launch_bounds__(kDefBlock) void k_cast_f(RenderParams p)
+__global__ __launch_bounds__(kDefBlock) GMUPT_CAST_OCCUPANCY void k_cast_f(RenderParams p)
 {
     GMUPT_DEF_LDS(TOP)
     shadow_counter_epilogue(p);
