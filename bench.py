@@ -137,6 +137,7 @@ def roofline_object(capi, s2, steps, cast_ms, scene, table_mb):
     ref_bytes = (s2.ext_rays * (4 + 24 + 48 + 32 * scene["light_count"] + 48) + 96 * s2.ext_inner + 52 * s2.ext_tris) / k
     if fused:
         ref_bytes += (s2.sh_rays * (4 + 24 + 4 + 48 + 4) + 96 * s2.sh_inner + 52 * s2.sh_tris) / k
+    profile = profile_figures("profiles/r02_config3")
     kname = "k_cast_f" if (s2.flags & capi.STAT_CAST_FETCH) else ("fused ray cast (variant)" if fused else "k_extend_d")
     return {"bound": "gather (random 64-byte records; vector-memory request rate)", "kernel": kname,
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "Grecords/s", "frac": round(achieved / peak, 4), "traffic": None,
@@ -153,7 +154,30 @@ def roofline_object(capi, s2, steps, cast_ms, scene, table_mb):
                     "hbm_peak_gbs": HBM_PEAK_GBS, "kernel_bytes_over_hbm_peak": round(kernel_bytes / sec / 1e9 / HBM_PEAK_GBS, 4) if sec > 0 else 0.0,
                     "note": "cache hits included: the BVH of this scene is L2 / Infinity-Cache resident; measured FETCH_SIZE / WRITE_SIZE per launch: see traffic_profile",
                     "traffic_profile": "profiles/r02_config3/ (pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this command)"},
+            "from_profile": profile,
             "reference_equivalent_bytes_per_launch": int(ref_bytes)}
+
+
+def profile_figures(directory):
+    """The counter-based figures of the committed profile of this command (tools/profile_round.sh + tools/roofline_summary.py): memory-side
+    bytes (raw FETCH_SIZE, the x2 = 128-byte-request reading, WRITE_SIZE) and the L1 access rate.  They were measured by a separate rocprofv3
+    run, NOT by this process -- they are carried with their source so that the line is self-contained, and are None when the file is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), directory, "roofline.json")
+    try:
+        with open(path) as f:
+            j = json.load(f)
+    except (OSError, ValueError):
+        return None
+    m = j.get("memory_side", {})
+    ms = j.get("avg_launch_ms_rocprof_trace") or 0.0
+    raw = m.get("FETCH_SIZE_bytes_raw", 0) + m.get("write_bytes", 0)
+    return {"source": directory + "/roofline.json (a separate rocprofv3 run of this command; not measured by this process)",
+            "avg_launch_ms_rocprof_trace": ms,
+            "memory_side_bytes_per_launch": {"FETCH_SIZE_raw": m.get("FETCH_SIZE_bytes_raw"), "read_128B_requests_x128": m.get("read_bytes"), "WRITE_SIZE": m.get("write_bytes")},
+            "memory_side_gbs": {"raw_FETCH_SIZE": round(raw / (ms * 1e-3) / 1e9, 1) if ms else None, "x2": m.get("gbs")},
+            "memory_side_over_hbm_peak": {"raw_FETCH_SIZE": round(raw / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms else None, "x2": m.get("frac_of_hbm_peak")},
+            "note": "Infinity-Cache (MALL) hits are inside these counters; every memory-side read request of this kernel is a 128-byte line, FETCH_SIZE tallies it at 64 bytes (profiles/r02_micro/fetch_size_calibration.txt)",
+            "vmem_request_rate": j.get("vmem_request_rate")}
 
 
 def main_rank(args):

@@ -4,6 +4,7 @@
 #   kernel_stats.csv    rocprofv3 --kernel-trace --stats of the same command (average launch durations)
 #   pmc_traffic.json    two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) summarised per launch by tools/pmc_summary.py
 #   pmc_counters.txt    per-kernel averages of the SQ / TCP / TCC / GRBM passes below (tools/pmc_table.py)
+#   ea_read_sizes.txt   the L2's memory-side read requests by size (TCC_EA0_RDREQ_{32B,64B,128B}); roofline.json = tools/roofline_summary.py over these files
 # Every profiled command is the program itself after `--` (no env / bash -c hop), every pass has its own `timeout -k`, and a pass holds at most
 # as many counters of a block as the block has slots (MI355X_MICROARCH.md "rocprofv3 PMC slots"; an over-subscribed pass aborts the profiled
 # process: profiles/README.md "TA counter pass").
@@ -32,7 +33,10 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
   i=$((i+1))
   timeout -k 10 400 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc/pass$i -- $CMD $SHORT > $OUT/pmc_pass$i.log 2>&1 || { echo "pmc pass $i ($set) failed"; tail -3 $OUT/pmc_pass$i.log; exit 1; }
 done
+timeout -k 10 400 rocprofv3 --pmc TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B TCC_EA0_RDREQ_DRAM --output-format csv -d $OUT/pmc_ea/pass1 -- $CMD $SHORT > $OUT/pmc_ea.log 2>&1 || { echo "pmc pass (read request sizes) failed"; tail -3 $OUT/pmc_ea.log; exit 1; }
+python3 tools/pmc_table.py $OUT/pmc_ea $SKIP > $OUT/ea_read_sizes.txt
 python3 tools/pmc_summary.py $OUT/pmc/pass1 $OUT/pmc/pass2 $OUT/pmc_traffic.json $SKIP > /dev/null
 python3 tools/pmc_table.py $OUT/pmc $SKIP > $OUT/pmc_counters.txt
-rm -rf $OUT/trace $OUT/pmc      # the raw per-dispatch CSVs stay on the box; the summaries above are what gets committed
+python3 tools/roofline_summary.py $OUT > /dev/null
+rm -rf $OUT/trace $OUT/pmc $OUT/pmc_ea      # the raw per-dispatch CSVs stay on the box; the summaries above are what gets committed
 ls $OUT

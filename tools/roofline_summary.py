@@ -32,5 +32,22 @@ out = {"kernel": "k_cast_f", "avg_launch_ms_hip_events": ms_event, "avg_launch_m
                        "note": "Infinity-Cache hits are inside these counters (they count the L2's memory-side requests)"},
        "records": {"per_launch": cast.get("global_records_per_launch") or cast.get("records_per_launch"),
                    "grecords_per_s": cast.get("grecords_per_s") or cast.get("achieved")}}
+# vector-memory request rate: L1 (TCP) accesses per clock and CU, from the per-kernel averages of the counter passes
+pmc, cur = {}, None
+try:
+    for line in open(d + "/pmc_counters.txt"):
+        if not line.startswith(" "): cur = line.strip(); continue
+        if cur and cur.startswith("k_cast_f"):
+            name, val = line.split(); pmc[name] = float(val)
+except FileNotFoundError:
+    pass
+if "TCP_TOTAL_CACHE_ACCESSES" in pmc and "GRBM_GUI_ACTIVE" in pmc:
+    CUS, XCDS = 256, 8
+    clocks = pmc["GRBM_GUI_ACTIVE"] / XCDS            # the counter is summed over the 8 XCDs
+    out["vmem_request_rate"] = {"l1_accesses_per_launch": int(pmc["TCP_TOTAL_CACHE_ACCESSES"]), "gpu_clocks_per_launch": int(clocks),
+                                "l1_accesses_per_clk_cu": round(pmc["TCP_TOTAL_CACHE_ACCESSES"] / clocks / CUS, 3),
+                                "l1_to_l2_read_requests": int(pmc.get("TCP_TCC_READ_REQ", 0)),
+                                "l2_hit_rate": round(pmc["TCC_HIT"] / pmc["TCC_REQ"], 3) if pmc.get("TCC_REQ") else None,
+                                "ceiling_note": "tools/micro/gather64 shape A: 1.05 per clock and CU with every record an L2 hit, 0.75 for a uniform 18.6 MB table (profiles/r02_micro/)"}
 json.dump(out, open(d + "/roofline.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
