@@ -251,6 +251,38 @@ def test_tile_and_budget_and_depth_extensions(pkg, device, cornell_scene):
     hip.close(); sb.close(); orc.close()
 
 
+def test_tile_split_is_statistically_the_single_pipeline_image(pkg, device, cornell_scene):
+    # an n-GPU image is not bitwise the 1-GPU image (the RNG seeds derive from local slot / queue indices); it must be the
+    # same image up to Monte-Carlo noise.  The yardstick is the difference between two single-pipeline renders with different seeds
+    # (another pool size): the two-band render may not differ from the reference render by more than that.
+    W, H, spp = 64, 36, 256
+    sb = pkg.capi.SceneBuffers(device, cornell_scene)
+
+    def render(width, rows, pool, tile):
+        r = pkg.capi.Renderer(device, width, rows, pool_paths=pool, tile=tile, path_budget=width * rows * spp)
+        r.bind_scene(sb)
+        cam = pkg.capi.Camera(W, H); cam.set_pose(*cornell_scene["camera"]); cam.buffer.lightCount = cornell_scene["light_count"]
+        r.render_budget(cam, 100000)
+        assert r.stats().paths_completed == width * rows * spp
+        fb = r.framebuffer(); r.close()
+        assert np.all(fb[..., 3].view(np.uint32) == spp)
+        return np.minimum(fb[..., :3].astype(np.float64), 4.0)   # clipped like a displayed image: single very bright samples would dominate an RMSE
+
+    single = render(W, H, 4096, None)
+    other_seeds = render(W, H, 3072, None)
+    bands = np.concatenate([render(W, rows, 4096, (0, y0)) for y0, rows in pkg.tiles.row_bands(H, 2)], axis=0)
+    sb.close()
+    assert bands.shape == single.shape and not np.array_equal(bands, single)
+    rmse = lambda a, b: float(np.sqrt(np.mean((a - b) ** 2)))
+    noise = rmse(single, other_seeds)
+    print("rmse single vs bands %.5f, single vs other seeds %.5f" % (rmse(single, bands), noise))
+    assert noise > 0.0 and rmse(single, bands) < 1.25 * noise, (rmse(single, bands), noise)
+    # no bias: the mean radiance of each band agrees within the noise of a band mean (the per-pixel noise / sqrt(pixels), with slack)
+    for y0, rows in pkg.tiles.row_bands(H, 2):
+        a, b = single[y0:y0 + rows], bands[y0:y0 + rows]
+        assert abs(a.mean() - b.mean()) < 6.0 * noise / np.sqrt(a.size), (y0, a.mean(), b.mean(), noise)
+
+
 def test_render_budget_helper_matches_oracle(pkg, device, soup_scene):
     g = np.load(os.path.join(GOLDEN, "soup2000_32x18_p1024_i16_budget.npz"))
     W, H, P, budget = int(g["width"]), int(g["height"]), int(g["pool"]), int(g["path_budget"])
