@@ -97,9 +97,9 @@ static_assert(sizeof(Node64) == 64 && sizeof(Tri48) == 48, "packed traversal rec
 struct alignas(64) Rec64 { float q[16]; };
 
 #ifndef GMUPT_TOP_NODES
-#define GMUPT_TOP_NODES 256
+#define GMUPT_TOP_NODES 768
 #endif
-constexpr int kTopTreeNodes = GMUPT_TOP_NODES; // inner nodes (breadth-first from the root) that the ray-cast kernels keep in LDS: 16 KB
+constexpr int kTopTreeNodes = GMUPT_TOP_NODES; // inner nodes (breadth-first from the root) that the ray-cast kernels keep in LDS: 48 KB
 
 struct TravScene {
     const Rec64* recs;

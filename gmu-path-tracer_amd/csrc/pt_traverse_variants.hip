@@ -860,11 +860,8 @@ struct TopStack {
 
 __device__ __forceinline__ void load_top_tree(const TravScene& ts, float4* s_top)
 {
-    // one 64-byte node per thread (kTravBlock == kTopTreeNodes == 256)
     const float4* src = reinterpret_cast<const float4*>(ts.nodes);
-    if (threadIdx.x < ts.topCount) {
-        for (int k = 0; k < 4; k++) s_top[threadIdx.x * 4 + k] = src[threadIdx.x * 4 + k];
-    }
+    for (uint32_t k = threadIdx.x; k < ts.topCount * 4u; k += kTravBlock) s_top[k] = src[k];
     __syncthreads();
 }
 
