@@ -42,6 +42,7 @@ void launch_detmath(int fn, const float* x, const float* y, float* out, uint32_t
 uint32_t traversal_block_threads();
 uint32_t deferred_block_threads();
 uint32_t traversal_overflow_entries();
+uint32_t traversal_top_capacity(uint32_t maxDepth);
 }
 using namespace gmupt;
 
@@ -355,18 +356,24 @@ static int build_traversal_copy(gmupt_renderer* r, const gmupt_buffer* nodesB, c
             numInner++;
         }
     }
-    // packed numbering: first the kTopTreeNodes inner nodes that the ray-cast kernels keep in LDS (the part of the tree every ray walks),
-    // then the remaining inner nodes in flatten order
+    std::vector<int32_t> depth(N, 0);
+    int32_t maxDepth = 0;
+    for (size_t i = 0; i < N; i++) if (!nodes[i].isLeaf) { depth[(size_t)nodes[i].left] = depth[i] + 1; depth[(size_t)nodes[i].right] = depth[i] + 1; }
+    for (size_t i = 0; i < N; i++) maxDepth = std::max(maxDepth, depth[i]);
+    // packed numbering: first the inner nodes that the ray-cast kernels keep in LDS (the part of the tree every ray walks), then the
+    // remaining inner nodes.  How many fit depends on the kernel instantiation this tree will run: a tree that needs the spilling stack
+    // keeps fewer stack entries and more nodes in LDS (pt_traverse_deferred.hpp: kDefLdsStack / kDefLdsTop)
+    const size_t topCapacity = traversal_top_capacity((uint32_t)maxDepth);
     {
         // the LDS-resident set grows from the root by always expanding the frontier node with the largest surface area (the usual
         // visit-probability estimate); GMUPT_TOP_ORDER=bfs selects plain breadth-first order (0.5 % slower on the bench scene)
-        std::vector<int32_t> bfs; bfs.reserve(kTopTreeNodes);
+        std::vector<int32_t> bfs; bfs.reserve(topCapacity);
         const char* order = std::getenv("GMUPT_TOP_ORDER");
         if (!(order && std::strcmp(order, "bfs") == 0)) {
             auto area = [&](int32_t i) { const gmupt_bvh_node& n = nodes[(size_t)i]; const double dx = (double)n.max[0] - n.min[0], dy = (double)n.max[1] - n.min[1], dz = (double)n.max[2] - n.min[2]; return dx * dy + dy * dz + dz * dx; };
             std::vector<std::pair<double, int32_t>> frontier;
             if (!nodes[0].isLeaf) frontier.push_back({ area(0), 0 });
-            while (!frontier.empty() && bfs.size() < (size_t)kTopTreeNodes) {
+            while (!frontier.empty() && bfs.size() < topCapacity) {
                 size_t best = 0;
                 for (size_t k = 1; k < frontier.size(); k++) if (frontier[k].first > frontier[best].first || (frontier[k].first == frontier[best].first && frontier[k].second < frontier[best].second)) best = k;
                 const int32_t v = frontier[best].second;
@@ -378,15 +385,16 @@ static int build_traversal_copy(gmupt_renderer* r, const gmupt_buffer* nodesB, c
             }
         } else {
             if (!nodes[0].isLeaf) bfs.push_back(0);
-            for (size_t h = 0; h < bfs.size() && bfs.size() < (size_t)kTopTreeNodes; h++) {
+            for (size_t h = 0; h < bfs.size() && bfs.size() < topCapacity; h++) {
                 const gmupt_bvh_node& n = nodes[(size_t)bfs[h]];
-                if (!nodes[(size_t)n.left].isLeaf && bfs.size() < (size_t)kTopTreeNodes) bfs.push_back(n.left);
-                if (!nodes[(size_t)n.right].isLeaf && bfs.size() < (size_t)kTopTreeNodes) bfs.push_back(n.right);
+                if (!nodes[(size_t)n.left].isLeaf && bfs.size() < topCapacity) bfs.push_back(n.left);
+                if (!nodes[(size_t)n.right].isLeaf && bfs.size() < topCapacity) bfs.push_back(n.right);
             }
         }
         int32_t nextIdx = 0;
         for (int32_t v : bfs) innerIndex[(size_t)v] = nextIdx++;
-        r->p.trav.topCount = (uint32_t)bfs.size();
+        r->p.trav.topCountDeep = (uint32_t)bfs.size();                                        // what the spilling-stack instantiations keep in LDS
+        r->p.trav.topCount = (uint32_t)std::min(bfs.size(), (size_t)kTopTreeNodes);             // what every other kernel keeps (a prefix of the same order)
         // The rest of the inner nodes.  Every memory-side read of the ray cast is a whole 128-byte line (TCC_EA0_RDREQ_128B is all of
         // TCC_EA0_RDREQ: profiles/r02_micro/fetch_size_calibration.txt), i.e. TWO 64-byte records.  A node therefore shares its line with the
         // inner child a ray is most likely to visit next (the one with the larger surface area): that visit then finds its record in the
@@ -425,8 +433,6 @@ static int build_traversal_copy(gmupt_renderer* r, const gmupt_buffer* nodesB, c
         // an empty leaf cannot be expressed by "first record + last flag": point it at a degenerate sentinel record
         return ~(c.right > c.left ? c.left : (int32_t)R);
     };
-    std::vector<int32_t> depth(N, 0);
-    for (size_t i = 0; i < N; i++) if (!nodes[i].isLeaf) { depth[(size_t)nodes[i].left] = depth[i] + 1; depth[(size_t)nodes[i].right] = depth[i] + 1; }
     std::vector<Node64> packed((size_t)numInner ? (size_t)numInner : 1);
     std::memset(packed.data(), 0, packed.size() * sizeof(Node64));
     for (size_t i = 0; i < N; i++) {
@@ -472,7 +478,7 @@ static int build_traversal_copy(gmupt_renderer* r, const gmupt_buffer* nodesB, c
     HIP_TRY(hipMemcpy(r->travRecs, recs.data(), recs.size() * sizeof(Rec64), hipMemcpyHostToDevice));
     TravScene& t = r->p.trav;
     t.recs = (const Rec64*)r->travRecs; t.triBase = (uint32_t)packed.size();
-    { int32_t md = 0; for (size_t i = 0; i < N; i++) md = std::max(md, depth[i]); t.maxDepth = (uint32_t)md; }
+    t.maxDepth = (uint32_t)maxDepth;
     t.nodes = (const Node64*)r->travNodes; t.tris = (const Tri48*)r->travTris;
     t.rootDesc = nodes[0].isLeaf ? ~(nodes[0].right > nodes[0].left ? nodes[0].left : (int32_t)R) : innerIndex[0];
     for (int k = 0; k < 3; k++) { t.rootMin[k] = nodes[0].min[k]; t.rootMax[k] = nodes[0].max[k]; }

@@ -99,6 +99,10 @@ struct alignas(64) Rec64 { float q[16]; };
 #ifndef GMUPT_TOP_NODES
 #define GMUPT_TOP_NODES 768
 #endif
+#ifndef GMUPT_DEEP_TOP_NODES
+#define GMUPT_DEEP_TOP_NODES 1280
+#endif
+constexpr int kDeepTopTreeNodes = GMUPT_DEEP_TOP_NODES; // the same for trees whose depth needs the spilling stack anyway: fewer stack entries in LDS, more of the tree (80 KB)
 constexpr int kTopTreeNodes = GMUPT_TOP_NODES; // inner nodes (breadth-first from the root) that the ray-cast kernels keep in LDS: 48 KB
 
 struct TravScene {
@@ -107,7 +111,8 @@ struct TravScene {
     const Node64* nodes;
     const Tri48* tris;
     int32_t rootDesc;
-    uint32_t topCount;     // nodes[0 .. topCount) are the breadth-first top of the tree
+    uint32_t topCount;     // nodes[0 .. topCount) are the top of the tree (largest surface area first) that fits the LDS of the plain layout
+    uint32_t topCountDeep; // the same for the layout of the spilling-stack instantiations (topCountDeep >= topCount: one numbering serves both)
     uint32_t maxDepth;     // depth of the deepest node (bounds the traversal stack)
     float rootMin[3], rootMax[3];
 };

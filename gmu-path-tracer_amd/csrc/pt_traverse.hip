@@ -302,7 +302,7 @@ __global__ __launch_bounds__(kDefBlock) GMUPT_CAST_OCCUPANCY void k_cast_f(Rende
             }
             // (b) owners that are done and have heard from all their helpers are written back now: their lanes become free
             const bool done = haveRay && owner < 0 && outstanding == 0u && cur == kDone && qCount == 0 && ti < 0;
-            const unsigned long long wantHelp = __ballot(haveRay && owner < 0 && stk.ptr > bottom && bottom + 1u < (uint32_t)kDefStack && donations < 12u);
+            const unsigned long long wantHelp = __ballot(haveRay && owner < 0 && stk.ptr > bottom && bottom + 1u < (uint32_t)kDefLdsStack<OVF> && donations < 12u);
             if (wantHelp != 0ull && done) {
                 if (kind == 0) {
                     if (refT >= 0 && tT < distance) { distance = tT; hu = uT; hv = vT; hitRef = refT; }
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(kDefBlock) GMUPT_CAST_OCCUPANCY void k_cast_f(Rende
             // fetch phase
             const bool doNode = cur >= 0;
             vec4f na, nb, nc; vec2i nd;                      // defined for the doNode lanes only
-            if (doNode) load_node_buf<TOP>(rNodes, s_top, ts.topCount, cur, na, nb, nc, nd);
+            if (doNode) load_node_buf<TOP>(rNodes, s_top, top_count<OVF>(ts), cur, na, nb, nc, nd);
             if (burst && ti < 0 && qCount > 0) { ti = fifo[(qHead & (kFifo - 1)) * kDefBlock]; qHead++; qCount--; }
             const bool doTri = burst && ti >= 0;
             vec4f r0, r1; vec2f r2;                          // defined for the doTri lanes only
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(kDefBlock) GMUPT_CAST_OCCUPANCY void k_cast_f(Rende
             // compute phase
             if (doNode) {
                 if (STATS) { if (kind == 0) { tcE.inner++; rayInner++; } else tcS.inner++; if (prefix_rank(__ballot(1)) == 0) { if (phase == 0) wInE++; else wInS++; }
-                             if (TOP && (uint32_t)cur < ts.topCount) { if (kind == 0) topE++; else topS++; } }
+                             if (TOP && (uint32_t)cur < top_count<OVF>(ts)) { if (kind == 0) topE++; else topS++; } }
                 cur = inner_compute_flat<OVF>(na, nb, nc, nd, o, invdir, stk, p.stats);
             }
             if (GMUPT_KNOCKOUT == 3) { if (cur < 0 && cur != kDone) cur = stk.pop(); }
@@ -581,9 +581,11 @@ uint32_t launch_shadow(const RenderParams& p, uint32_t blocks, bool stats, int m
 
 uint32_t traversal_block_threads() { return kTravBlock; }
 uint32_t deferred_block_threads() { return kDefBlock; }
+// nodes of the tree top the ray casts of a tree of this depth keep in LDS (the spilling-stack instantiations hold more, see kDefLdsTop)
+uint32_t traversal_top_capacity(uint32_t maxDepth) { return maxDepth + 2 > (uint32_t)kDefStack ? (uint32_t)kDeepTopTreeNodes : (uint32_t)kTopTreeNodes; }
 uint32_t traversal_overflow_entries()
 {
-    uint32_t a = (uint32_t)(kMaxStack + 1 - kDefStack);
+    uint32_t a = (uint32_t)(kMaxStack + 1 - kDeepStack);
 #ifdef GMUPT_VARIANTS
     const uint32_t b = variant_overflow_entries(); if (b > a) a = b;
 #endif

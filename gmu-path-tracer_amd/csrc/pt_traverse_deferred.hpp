@@ -29,6 +29,18 @@ constexpr int kFifo = GMUPT_DEF_FIFO;          // pending leaves per lane
 // A larger top is worth more than a second workgroup's copy of a smaller one: 60 -> 68 % of the node visits of the bench scene and
 // 46 -> 59 % of those of the 10 M-triangle scene are served from LDS (ray cast -1 % / -13 %).
 static_assert((kDefStack + kFifo) * kDefBlock * 4 + kTopTreeNodes * 64 <= 160 * 1024, "LDS of one CU");
+// Trees deeper than kDefStack - 2 run the instantiations with a bounds-checked global overflow (OVF).  They pay for the check anyway, so
+// their LDS holds only kDeepStack entries per lane and the freed 32 KB hold more of the tree (10 M-triangle scene: 59 -> 63 % of the node
+// visits from LDS, ray cast -3 %; on a shallow tree the check alone costs +4 %, so the plain layout keeps its 24 entries).
+#ifndef GMUPT_DEEP_STACK
+#define GMUPT_DEEP_STACK 16
+#endif
+constexpr int kDeepStack = GMUPT_DEEP_STACK;
+template <bool OVF> constexpr int kDefLdsStack = OVF ? kDeepStack : kDefStack;
+template <bool OVF> constexpr int kDefLdsTop = OVF ? kDeepTopTreeNodes : kTopTreeNodes;
+template <bool OVF> __device__ __forceinline__ uint32_t top_count(const TravScene& ts) { return OVF ? ts.topCountDeep : ts.topCount; }
+static_assert((kDeepStack + kFifo) * kDefBlock * 4 + kDeepTopTreeNodes * 64 <= 160 * 1024, "LDS of one CU (deep-tree layout)");
+static_assert(kDeepStack <= kDefStack && kDeepTopTreeNodes >= kTopTreeNodes, "the two layouts share one node numbering and one overflow buffer");
 static_assert((kFifo & (kFifo - 1)) == 0, "the leaf FIFO is indexed modulo its size");
 
 template <bool OVF>
@@ -37,16 +49,16 @@ struct DefStack {
     __device__ __forceinline__ void reset() { ptr = 1; }
     __device__ __forceinline__ void push(int v, DevStats* st)
     {
-        if (!OVF || ptr < kDefStack) lds[ptr * kDefBlock] = v;
-        else if (ptr < kMaxStack + 1) ovf[(size_t)(ptr - kDefStack) * ovfStride] = v;
+        if (!OVF || ptr < kDefLdsStack<OVF>) lds[ptr * kDefBlock] = v;
+        else if (ptr < kMaxStack + 1) ovf[(size_t)(ptr - kDefLdsStack<OVF>) * ovfStride] = v;
         else st->stackOverflow = 1u;
         ptr++;
     }
     __device__ __forceinline__ int pop()
     {
         --ptr;
-        if (!OVF || ptr < kDefStack) return lds[ptr * kDefBlock];
-        if (ptr < kMaxStack + 1) return ovf[(size_t)(ptr - kDefStack) * ovfStride];
+        if (!OVF || ptr < kDefLdsStack<OVF>) return lds[ptr * kDefBlock];
+        if (ptr < kMaxStack + 1) return ovf[(size_t)(ptr - kDefLdsStack<OVF>) * ovfStride];
         return kDone;
     }
 };
@@ -61,11 +73,11 @@ typedef int vec2i __attribute__((ext_vector_type(2)));
 #define GMUPT_AS_GLOBAL __attribute__((address_space(1)))
 
 template <bool TOP>
-__device__ __forceinline__ void load_node(const TravScene& ts, const float4* s_top, int cur, vec4f& a, vec4f& b, vec4f& c, vec2i& d)
+__device__ __forceinline__ void load_node(const TravScene& ts, const float4* s_top, uint32_t topCount, int cur, vec4f& a, vec4f& b, vec4f& c, vec2i& d)
 {
     // LDS lanes first: the global lanes then only wait for the (short) LDS reads before their loads may target the same registers,
     // and nothing waits for the global loads before they are used
-    const bool inTop = TOP && (uint32_t)cur < ts.topCount;
+    const bool inTop = TOP && (uint32_t)cur < topCount;
     if (inTop) {
         const GMUPT_AS_LDS vec4f* n = (const GMUPT_AS_LDS vec4f*)(s_top) + cur * 4;
         a = n[0]; b = n[1]; c = n[2]; d = *(const GMUPT_AS_LDS vec2i*)(n + 3);
@@ -153,7 +165,7 @@ template <bool OVF, bool TOP>
 __device__ __forceinline__ int inner_step_d(const TravScene& ts, const float4* s_top, int cur, f3 o, f3 invdir, DefStack<OVF>& stk, DevStats* dst)
 {
     vec4f a, b, c; vec2i d;
-    load_node<TOP>(ts, s_top, cur, a, b, c, d); // the first levels of the tree live in LDS (48 % of all inner-node visits on the bench scene)
+    load_node<TOP>(ts, s_top, top_count<OVF>(ts), cur, a, b, c, d); // the first levels of the tree live in LDS (48 % of all inner-node visits on the bench scene)
     return inner_compute<OVF>(a, b, c, d, o, invdir, stk, dst);
 }
 
@@ -171,7 +183,7 @@ template <bool OVF, bool TOP>
 __device__ __forceinline__ int inner_step_pruned(const TravScene& ts, const float4* s_top, int cur, f3 o, f3 invdir, float limitT, DefStack<OVF>& stk, DevStats* dst)
 {
     vec4f a, b, c; vec2i d;
-    load_node<TOP>(ts, s_top, cur, a, b, c, d);
+    load_node<TOP>(ts, s_top, top_count<OVF>(ts), cur, a, b, c, d);
     float le, re;
     const float leftHit = ray_box_entry(a.x, a.y, a.z, a.w, b.x, b.y, o, invdir, le);
     const float rightHit = ray_box_entry(b.z, b.w, c.x, c.y, c.z, c.w, o, invdir, re);
@@ -184,12 +196,12 @@ __device__ __forceinline__ int inner_step_pruned(const TravScene& ts, const floa
 
 // LDS of one workgroup of the deferred-leaf kernels: traversal stacks, leaf FIFOs, top of the tree
 #define GMUPT_DEF_LDS(TOP) \
-    __shared__ int s_stack[kDefStack * kDefBlock]; \
+    __shared__ int s_stack[kDefLdsStack<OVF> * kDefBlock]; \
     __shared__ int s_fifo[kFifo * kDefBlock]; \
-    __shared__ float4 s_top[TOP ? kTopTreeNodes * 4 : 4]; \
+    __shared__ float4 s_top[TOP ? kDefLdsTop<OVF> * 4 : 4]; \
     if (TOP) { \
         const float4* src = reinterpret_cast<const float4*>(p.trav.nodes); \
-        for (uint32_t k = threadIdx.x; k < p.trav.topCount * 4u; k += kDefBlock) s_top[k] = src[k]; \
+        for (uint32_t k = threadIdx.x; k < top_count<OVF>(p.trav) * 4u; k += kDefBlock) s_top[k] = src[k]; \
         __syncthreads(); \
     }
 

@@ -1474,12 +1474,12 @@ constexpr int kPrefetchBatch = 8;   // request new queue entries when this many 
 template <bool STATS, bool OVF, bool TOP, int REPS, int BURST>
 __global__ __launch_bounds__(kDefBlock) void k_extend_e(RenderParams p)
 {
-    __shared__ int s_stack[kDefStack * kDefBlock];
+    __shared__ int s_stack[kDefLdsStack<OVF> * kDefBlock];
     __shared__ int s_fifo[kFifo * kDefBlock];
-    __shared__ float4 s_top[TOP ? kTopTreeNodes * 4 : 4];
+    __shared__ float4 s_top[TOP ? kDefLdsTop<OVF> * 4 : 4];
     if (TOP) {
         const float4* src = reinterpret_cast<const float4*>(p.trav.nodes);
-        for (uint32_t k = threadIdx.x; k < p.trav.topCount * 4u; k += kDefBlock) s_top[k] = src[k];
+        for (uint32_t k = threadIdx.x; k < top_count<OVF>(p.trav) * 4u; k += kDefBlock) s_top[k] = src[k];
         __syncthreads();
     }
     const uint32_t gtid = blockIdx.x * kDefBlock + threadIdx.x;
@@ -1605,12 +1605,12 @@ __global__ __launch_bounds__(kDefBlock) void k_extend_e(RenderParams p)
 template <bool STATS, bool OVF, bool TOP, int REPS, int BURST>
 __global__ __launch_bounds__(kDefBlock) void k_shadow_e(RenderParams p)
 {
-    __shared__ int s_stack[kDefStack * kDefBlock];
+    __shared__ int s_stack[kDefLdsStack<OVF> * kDefBlock];
     __shared__ int s_fifo[kFifo * kDefBlock];
-    __shared__ float4 s_top[TOP ? kTopTreeNodes * 4 : 4];
+    __shared__ float4 s_top[TOP ? kDefLdsTop<OVF> * 4 : 4];
     if (TOP) {
         const float4* src = reinterpret_cast<const float4*>(p.trav.nodes);
-        for (uint32_t k = threadIdx.x; k < p.trav.topCount * 4u; k += kDefBlock) s_top[k] = src[k];
+        for (uint32_t k = threadIdx.x; k < top_count<OVF>(p.trav) * 4u; k += kDefBlock) s_top[k] = src[k];
     }
     const uint32_t gtid = blockIdx.x * kDefBlock + threadIdx.x;
     const uint32_t count = p.qc[QC_SHADOWRAY];                               // shadowRayCast.hlsl:151
