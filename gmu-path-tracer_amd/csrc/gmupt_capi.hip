@@ -465,7 +465,8 @@ static int build_traversal_copy(gmupt_renderer* r, const gmupt_buffer* nodesB, c
     HIP_TRY(hipMalloc(&r->travTris, ptris.size() * sizeof(Tri48)));
     HIP_TRY(hipMemcpy(r->travNodes, packed.data(), packed.size() * sizeof(Node64), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(r->travTris, ptris.data(), ptris.size() * sizeof(Tri48), hipMemcpyHostToDevice));
-    // unified 64-byte records for the cooperative kernels
+#ifdef GMUPT_VARIANTS
+    // unified 64-byte records for the cooperative kernels (rungs of the test build only)
     std::vector<Rec64> recs(packed.size() + ptris.size());
     std::memset(recs.data(), 0, recs.size() * sizeof(Rec64));
     for (size_t i = 0; i < packed.size(); i++) std::memcpy(&recs[i], &packed[i], 64);
@@ -476,6 +477,7 @@ static int build_traversal_copy(gmupt_renderer* r, const gmupt_buffer* nodesB, c
     if (r->travRecs) { HIP_TRY(hipFree(r->travRecs)); r->travRecs = nullptr; }
     HIP_TRY(hipMalloc(&r->travRecs, recs.size() * sizeof(Rec64)));
     HIP_TRY(hipMemcpy(r->travRecs, recs.data(), recs.size() * sizeof(Rec64), hipMemcpyHostToDevice));
+#endif
     TravScene& t = r->p.trav;
     t.recs = (const Rec64*)r->travRecs; t.triBase = (uint32_t)packed.size();
     t.maxDepth = (uint32_t)maxDepth;
