@@ -275,14 +275,36 @@ __global__ __launch_bounds__(kDefBlock) GMUPT_CAST_OCCUPANCY void k_cast_f(Rende
     int owner = -1;               // >= 0: this lane walks a subtree donated by lane `owner` (same ray, own stack, own leaf FIFO)
     uint32_t bottom = 1;          // lowest live entry of this lane's stack (entries below it were donated; the slot under it holds the sentinel)
     uint32_t outstanding = 0;     // owner: helpers that have not reported yet
-    uint32_t donations = 0;       // owner: subtrees donated so far; helper: the number of its donation
+    uint32_t donations = 0;       // subtrees this lane has donated so far (a helper donates parts of its subtree in turn)
+    uint32_t dno = 0;             // helper: the number of its donation at its owner
     float tT = kFltMax, uT = 0.0f, vT = 0.0f; int refT = -1; uint32_t dT = 0;   // owner: best helper result so far (by t, then by LATER donation)
     const uint32_t lane = threadIdx.x & 63u;
 
+#ifdef GMUPT_LOOP_CAP
+    uint32_t loopCount = 0;
+#endif
     for (;;) {
+#ifdef GMUPT_LOOP_CAP
+        if (++loopCount > (uint32_t)GMUPT_LOOP_CAP) {   // debugging aid: a wave that does not end reports the state of its lanes and leaves
+            const unsigned long long mHave = __ballot(haveRay), mHelper = __ballot(haveRay && owner >= 0), mOut = __ballot(outstanding != 0u),
+                                     mWalk = __ballot(cur >= 0), mLeaf = __ballot(cur < 0 && cur != kDone), mPend = __ballot(qCount > 0 || ti >= 0);
+            if (lane == 0u && atomicAdd(&p.stats->castWaveEndHist[31], 1ull) == 0ull) {
+                p.stats->castWaveEndHist[0] = mHave; p.stats->castWaveEndHist[1] = mHelper; p.stats->castWaveEndHist[2] = mOut;
+                p.stats->castWaveEndHist[3] = mWalk; p.stats->castWaveEndHist[4] = mLeaf; p.stats->castWaveEndHist[5] = mPend;
+                p.stats->castWaveEndHist[6] = (unsigned long long)phase; p.stats->castWaveEndHist[7] = (unsigned long long)blockIdx.x * 100ull + (threadIdx.x >> 6);
+            }
+            if (mHave >> lane & 1ull) { p.stats->castWaveEndHist[8 + (lane & 15u)] = ((unsigned long long)(uint32_t)owner << 32) | (outstanding << 16) | (stk.ptr << 8) | bottom; }
+            break;
+        }
+#endif
         if (phase == 2) { // wave-uniform: drain service
             // (a) helpers that have finished their subtree report to their owner
-            unsigned long long fin = __ballot(haveRay && owner >= 0 && cur == kDone && qCount == 0 && ti < 0);
+            const bool reports = haveRay && owner >= 0 && outstanding == 0u && cur == kDone && qCount == 0 && ti < 0;
+            if (reports) {   // what its own helpers found in the parts it gave away: later in visit order than its own walk, so only if strictly closer
+                if (kind == 0) { if (refT >= 0 && tT < distance) { distance = tT; hu = uT; hv = vT; hitRef = refT; } }
+                else if (refT >= 0) hitRef = refT;
+            }
+            unsigned long long fin = __ballot(reports);
             while (fin) {
                 const int hl = __builtin_ctzll(fin); fin &= fin - 1ull;
                 const int ol = __builtin_amdgcn_readlane(owner, hl);
@@ -290,7 +312,7 @@ __global__ __launch_bounds__(kDefBlock) GMUPT_CAST_OCCUPANCY void k_cast_f(Rende
                 const float uh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hu), hl));
                 const float vh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hv), hl));
                 const int rh = __builtin_amdgcn_readlane(hitRef, hl);
-                const uint32_t dh = (uint32_t)__builtin_amdgcn_readlane((int)donations, hl);
+                const uint32_t dh = (uint32_t)__builtin_amdgcn_readlane((int)dno, hl);
                 if ((int)lane == ol) {
                     outstanding--;
                     if (rh >= 0) {
@@ -298,11 +320,12 @@ __global__ __launch_bounds__(kDefBlock) GMUPT_CAST_OCCUPANCY void k_cast_f(Rende
                         else if (th < tT || (th == tT && dh > dT)) { tT = th; uT = uh; vT = vh; refT = rh; dT = dh; }
                     }
                 }
-                if ((int)lane == hl) { haveRay = false; owner = -1; }
+                if ((int)lane == hl) { haveRay = false; owner = -1; tT = kFltMax; refT = -1; dT = 0; }
             }
             // (b) owners that are done and have heard from all their helpers are written back now: their lanes become free
             const bool done = haveRay && owner < 0 && outstanding == 0u && cur == kDone && qCount == 0 && ti < 0;
-            const unsigned long long wantHelp = __ballot(haveRay && owner < 0 && stk.ptr > bottom && bottom + 1u < (uint32_t)kDefLdsStack<OVF> && donations < 12u);
+            // (a lane whose walk has ended never gives: an occluded shadow ray leaves its stack behind, and those subtrees no longer matter)
+            const unsigned long long wantHelp = __ballot(haveRay && cur != kDone && stk.ptr > bottom && bottom + 1u < (uint32_t)kDefLdsStack<OVF> && donations < 12u);
             if (wantHelp != 0ull && done) {
                 if (kind == 0) {
                     if (refT >= 0 && tT < distance) { distance = tT; hu = uT; hv = vT; hitRef = refT; }
@@ -334,16 +357,18 @@ __global__ __launch_bounds__(kDefBlock) GMUPT_CAST_OCCUPANCY void k_cast_f(Rende
                 const float ox = __shfl(o.x, sl), oy = __shfl(o.y, sl), oz = __shfl(o.z, sl), dx = __shfl(d.x, sl), dy = __shfl(d.y, sl), dz = __shfl(d.z, sl);
                 const float lim = __shfl(distance, sl);
                 if (takes) {
-                    haveRay = true; owner = src; kind = k2; index = (uint32_t)i2; donations = (uint32_t)n2;
+                    haveRay = true; owner = src; kind = k2; index = (uint32_t)i2; dno = (uint32_t)n2; donations = 0;
                     o = mk3(ox, oy, oz); d = mk3(dx, dy, dz); invdir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                     distance = k2 == 1 ? lim : kFltMax;     // shadow: the distance of the light; extension: no hit yet
                     hitRef = -1; hu = 0.0f; hv = 0.0f;
                     stk.reset(); bottom = 1; outstanding = 0; qHead = 0; qCount = 0; ti = -1;
+                    tT = kFltMax; refT = -1; dT = 0;
                     cur = node2;
                 }
             }
         }
-        const bool idle = (cur == kDone) && (qCount == 0) && (ti < 0);
+        // (a helper, or a lane that still waits for its helpers, is not idle: it has a report to make or to receive)
+        const bool idle = (cur == kDone) && (qCount == 0) && (ti < 0) && !(haveRay && (owner >= 0 || outstanding != 0u));
         const unsigned long long idleMask = __ballot(idle);
         const int nIdle = __popcll(idleMask);
         if (nIdle == 64 || (nIdle >= (int)p.tuneRefill && phase < 2)) { // wave-uniform
