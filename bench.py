@@ -16,9 +16,10 @@ Steady state needs care: the reference has no depth limit and kills paths by Rus
 (logic.hlsl:248-255), so in this closed room ~55 % of the paths end at length 201 and a pool that starts in lock-step
 completes paths in bursts with a period of 201 iterations (damping 0.55 per period).  The default pre-warm is ten periods
 (2010 iterations, ~3 s) and the default K is one period (201), which makes the value independent of the phase.
-With N GPUs the frame is split into N row bands (one private pipeline per rank, no data-path collective); the timed region
-ends with the RCCL gather of the tiles to rank 0 (the assembled frame stays on rank 0's GPU: the metric excludes scene build / upload
-and the final host read-back).  What is scaled ("weak"): the per-GPU pool is fixed, so every rank does one wavefront
+With N GPUs the frame is split into N row bands (one private pipeline per rank, no data-path collective); the K timed steps are
+bracketed by a barrier and a device synchronisation on both sides.  The RCCL gather of the tiles to rank 0 happens once per frame, not
+once per K steps: it is timed on its own right after (`tile_gather_ms`) and is inside the `full_frame` leg (the assembled frame stays on
+rank 0's GPU: the metric excludes scene build / upload and the final host read-back).  What is scaled ("weak"): the per-GPU pool is fixed, so every rank does one wavefront
 iteration over 2^21 paths per step whatever N is; the frame it fills is 1/N of the image.
 
 Besides `value` the line carries
@@ -261,10 +262,16 @@ def main_rank(args):
     barrier()
     t_start = time.perf_counter()
     step(r, cam, args.steps)
+    r.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    # the tile gather happens once per FRAME (thousands of steps), not once per K steps: it is timed on its own here and is part of the
+    # full_frame leg below, where it belongs
+    t_gather = time.perf_counter()
     r.copy_framebuffer_to_device(tile_t.data_ptr(), tile_t.numel() * 4)  # synchronises the renderer's stream
     frame = tiles.gather_tiles(tile_t if coll_dev == "cuda" else tile_t.cpu(), W, H, rank, world, dist if world > 1 else None)
     barrier()
-    elapsed = time.perf_counter() - t_start
+    gather_ms = (time.perf_counter() - t_gather) * 1e3
 
     st = r.stats()
     r.enable_timing(0)
@@ -273,6 +280,7 @@ def main_rank(args):
     r.reset_stats(); r.enable_timing(1); step(r, cam, 50); stb = r.stats(); r.enable_timing(0)
     total_paths, total_segments = all_sum([float(st.paths_completed), float(st.segments)])
     elapsed = all_max(elapsed)
+    gather_ms = all_max(gather_ms)
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -320,7 +328,7 @@ def main_rank(args):
             "metric": "Mpaths/s @1920x1080x64spp, 260k-tri scene", "value": round(value, 3), "unit": "Mpaths/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "headline": "value = completed paths / wall time of the K timed steady-state steps (all ranks); full_frame = the whole W*H*spp job incl. ramp-up and drain",
+            "headline": "value = completed paths / wall time of the K timed steady-state steps (all ranks; barrier + device synchronisation on both sides); tile_gather_ms = one gather of the tiles to rank 0, which happens once per frame and is inside full_frame = the whole W*H*spp job incl. ramp-up, drain and gather",
             "config": {"workload": "config3: %d-tri seeded sphere room (%d nodes), %dx%d, %d spp steady state, UE4+glass+NEE, unbounded depth"
                        % (scene["num_triangles"], scene["nodes"].shape[0], W, H, args.spp),
                        "pool_paths_per_gpu": args.pool, "prewarm_steps": args.prewarm, "tiling": "row bands x%d" % world,
@@ -329,7 +337,7 @@ def main_rank(args):
             "msegments_per_s": round(total_segments / elapsed / 1e6, 1),
             "stage_ms": {"logic": round(stb.ms_logic / max(stb.timed_iterations, 1), 4), "material": round(stb.ms_material / max(stb.timed_iterations, 1), 4),
                          "raycast": round(cast_ms, 4), "shadow_separate": round(stb.ms_shadow / max(stb.timed_iterations, 1), 4)},
-            "scene_build_s": round(build_s, 2),
+            "tile_gather_ms": round(gather_ms, 3), "scene_build_s": round(build_s, 2),
             "full_frame": full_frame, "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out), flush=True)
