@@ -47,7 +47,7 @@ class RendererDesc(C.Structure):
                 ("path_budget", C.c_uint32), ("max_depth", C.c_uint32), ("collect_stats", C.c_uint32)]
 
 
-STAT_STACK_OVERFLOW, STAT_FUSED_CAST, STAT_CAST_FETCH, STAT_STACK_SPILL = 1, 2, 4, 8
+STAT_STACK_OVERFLOW, STAT_FUSED_CAST, STAT_CAST_FETCH, STAT_STACK_SPILL, STAT_CAST_ABORTED = 1, 2, 4, 8, 16
 
 
 class Stats(C.Structure):

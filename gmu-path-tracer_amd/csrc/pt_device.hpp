@@ -62,7 +62,7 @@ struct DevStats {
     unsigned long long extTopInner, shTopInner; // inner-node visits served by the LDS-resident top of the tree (no vector-memory request)
     unsigned long long castHelperSubtrees;      // subtrees handed to idle lanes in the drain of the fused ray cast
     uint32_t activePaths;
-    uint32_t stackOverflow; // traversal needed more than the provisioned stack (results then differ from an unbounded stack)
+    uint32_t stackOverflow; // bit 0: traversal needed more than the provisioned stack (results then differ from an unbounded stack); bit 1: a wave of the fused ray cast left at its iteration limit
 };
 
 struct alignas(16) DNode { float4 mn; float4 mx; int4 link; }; // gmupt_bvh_node, 48 B: link = (left, right, isLeaf, pad)
@@ -144,6 +144,7 @@ struct RenderParams {
     uint32_t extendPrune;  // 1: the extension ray skips boxes it enters beyond its current closest hit (see pt_traverse.hip)
     uint32_t shadowPrune;  // 1: the shadow ray skips boxes it enters beyond the light (cannot change its boolean result)
     uint32_t tuneRefill, tuneTriThresh; // lane-refill / triangle-burst thresholds of the deferred-leaf kernels
+    uint32_t castLoopCap;  // watchdog of the fused ray cast: loop iterations after which a wave gives up (GMUPT_STAT_CAST_ABORTED)
     gmupt_camera_buffer cam;
     SceneView scene;
     TravScene trav;

@@ -280,12 +280,14 @@ __global__ __launch_bounds__(kDefBlock) GMUPT_CAST_OCCUPANCY void k_cast_f(Rende
     float tT = kFltMax, uT = 0.0f, vT = 0.0f; int refT = -1; uint32_t dT = 0;   // owner: best helper result so far (by t, then by LATER donation)
     const uint32_t lane = threadIdx.x & 63u;
 
-#ifdef GMUPT_LOOP_CAP
+    // Watchdog: a persistent kernel must end whatever happens.  A wave of the bench scene runs ~150 loop iterations per launch, one of the
+    // 10 M-triangle scene ~600; a wave that reaches the limit has met a bug in the hand-over protocol of the drain: it flags the launch
+    // (GMUPT_STAT_CAST_ABORTED: results invalid) and leaves.  -DGMUPT_LOOP_DUMP also records the state of its lanes (debugging aid).
     uint32_t loopCount = 0;
-#endif
     for (;;) {
-#ifdef GMUPT_LOOP_CAP
-        if (++loopCount > (uint32_t)GMUPT_LOOP_CAP) {   // debugging aid: a wave that does not end reports the state of its lanes and leaves
+        if (++loopCount > p.castLoopCap) {   // (2^20 by default; GMUPT_CAST_LOOP_CAP)
+            if (lane == 0u) atomicOr(&p.stats->stackOverflow, 2u);
+#ifdef GMUPT_LOOP_DUMP
             const unsigned long long mHave = __ballot(haveRay), mHelper = __ballot(haveRay && owner >= 0), mOut = __ballot(outstanding != 0u),
                                      mWalk = __ballot(cur >= 0), mLeaf = __ballot(cur < 0 && cur != kDone), mPend = __ballot(qCount > 0 || ti >= 0);
             if (lane == 0u && atomicAdd(&p.stats->castWaveEndHist[31], 1ull) == 0ull) {
@@ -294,9 +296,9 @@ __global__ __launch_bounds__(kDefBlock) GMUPT_CAST_OCCUPANCY void k_cast_f(Rende
                 p.stats->castWaveEndHist[6] = (unsigned long long)phase; p.stats->castWaveEndHist[7] = (unsigned long long)blockIdx.x * 100ull + (threadIdx.x >> 6);
             }
             if (mHave >> lane & 1ull) { p.stats->castWaveEndHist[8 + (lane & 15u)] = ((unsigned long long)(uint32_t)owner << 32) | (outstanding << 16) | (stk.ptr << 8) | bottom; }
+#endif
             break;
         }
-#endif
         if (phase == 2) { // wave-uniform: drain service
             // (a) helpers that have finished their subtree report to their owner
             const bool reports = haveRay && owner >= 0 && outstanding == 0u && cur == kDone && qCount == 0 && ti < 0;

@@ -156,6 +156,8 @@ int gmupt_synchronize(gmupt_renderer* r);
 #define GMUPT_STAT_STACK_OVERFLOW 1u /* a traversal stack exceeded 64 entries (results invalid; never seen on a builder-made tree) */
 #define GMUPT_STAT_FUSED_CAST 2u     /* both ray casts ran as one launch: ms_extend is the time of that launch, ms_shadow is 0 */
 #define GMUPT_STAT_CAST_FETCH 4u     /* that launch was k_cast_f (the default kernel; it needs node / triangle arrays below 2 GiB each) */
+#define GMUPT_STAT_CAST_ABORTED 16u  /* a wave of the fused ray cast left its loop at the iteration limit (2^20 loop iterations; a bench-scene wave runs
+                                        ~150): a defect, results invalid -- the kernel ends whatever happens */
 #define GMUPT_STAT_STACK_SPILL 8u    /* the tree is deeper than the LDS part of the traversal stacks: the instantiation with the bounds-checked
                                         global spill ran (results are the same; GMUPT_STAT_STACK_OVERFLOW is the error flag) */
 typedef struct {

@@ -432,3 +432,27 @@ def test_error_convention_on_device(pkg, device, cornell_scene):
     with pytest.raises(capi.GmuptError):
         capi.Device(99)
     r.close(); sb.close()
+
+
+def test_ray_cast_watchdog_ends_the_launch_and_flags_it(pkg, device, spheres_small_scene, monkeypatch):
+    # the persistent ray-cast kernel must end whatever happens: with the iteration limit set absurdly low every wave gives up at once,
+    # the launch returns and the statistics say that its results are invalid; with the default limit the flag stays clear
+    capi = pkg.capi
+    sb = capi.SceneBuffers(device, spheres_small_scene)
+
+    def run(cap):
+        if cap: monkeypatch.setenv("GMUPT_CAST_LOOP_CAP", str(cap))
+        else: monkeypatch.delenv("GMUPT_CAST_LOOP_CAP", raising=False)
+        r = capi.Renderer(device, 96, 54, pool_paths=1 << 16)
+        r.bind_scene(sb)
+        cam = capi.Camera(96, 54); cam.set_pose(*spheres_small_scene["camera"]); cam.buffer.lightCount = spheres_small_scene["light_count"]
+        for _ in range(6):
+            cam.update(0.0); r.set_camera(cam.buffer); r.iterate()
+        r.synchronize()
+        flags = r.stats().flags
+        r.close()
+        return flags
+
+    assert run(2) & capi.STAT_CAST_ABORTED
+    assert not (run(0) & (capi.STAT_CAST_ABORTED | capi.STAT_STACK_OVERFLOW))
+    sb.close()
