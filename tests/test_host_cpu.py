@@ -96,6 +96,18 @@ def test_capi_exports_every_declared_symbol(pkg):
     assert lib.gmupt_version().startswith(b"gmupt")
 
 
+def test_binding_constants_follow_the_header(pkg):
+    # the ctypes binding restates enum values and flag bits of include/gmupt.h: they must not drift apart
+    header = open(os.path.join(ROOT, "include", "gmupt.h")).read()
+    capi = pkg.capi
+    for name, value in re.findall(r"#define\s+GMUPT_STAT_([A-Z_]+)\s+(\d+)u", header):
+        assert getattr(capi, "STAT_" + name) == int(value), name
+    for name, value in re.findall(r"GMUPT_BUFFER_([A-Z_]+)\s*=\s*(\d+)", header):
+        assert getattr(capi, "BUFFER_" + name) == int(value), name
+    assert int(re.search(r"#define\s+GMUPT_STATE_BYTES\s+(\d+)u", header).group(1)) == capi.STATE_BYTES == 248
+    assert C.sizeof(capi.CameraBuffer) == 112 if hasattr(capi, "CameraBuffer") else True
+
+
 def test_capi_error_convention(pkg):
     lib = pkg.capi.lib()
     assert lib.gmupt_iterate(None) == -1 and b"null" in lib.gmupt_last_error()
