@@ -274,6 +274,8 @@ def main_rank(args):
     gather_ms = (time.perf_counter() - t_gather) * 1e3
 
     st = r.stats()
+    if st.flags & (capi.STAT_STACK_OVERFLOW | capi.STAT_CAST_ABORTED):
+        raise SystemExit("bench.py: the ray cast reported an error (gmupt_stats.flags = %#x): the numbers would be invalid" % st.flags)
     r.enable_timing(0)
     cast_ms = st.ms_extend / max(st.timed_iterations, 1)
     # per-stage breakdown: a short untimed continuation with events around every stage group
@@ -315,6 +317,8 @@ def main_rank(args):
         barrier()
         ff_s = time.perf_counter() - t1
         sf = rf.stats()
+        if sf.flags & (capi.STAT_STACK_OVERFLOW | capi.STAT_CAST_ABORTED):
+            raise SystemExit("bench.py: the ray cast reported an error in the full-frame leg (gmupt_stats.flags = %#x)" % sf.flags)
         done, cut = all_sum([float(sf.paths_completed), float(sf.active_paths)])
         ff_s = all_max(ff_s); iters = int(all_max(float(iters)))
         rf.close(); del fr
