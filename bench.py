@@ -155,6 +155,7 @@ def roofline_object(capi, s2, steps, cast_ms, scene, table_mb):
                     "hbm_peak_gbs": HBM_PEAK_GBS, "kernel_bytes_over_hbm_peak": round(kernel_bytes / sec / 1e9 / HBM_PEAK_GBS, 4) if sec > 0 else 0.0,
                     "note": "cache hits included: the BVH of this scene is L2 / Infinity-Cache resident; measured FETCH_SIZE / WRITE_SIZE per launch: see traffic_profile",
                     "traffic_profile": "profiles/r02_config3/ (pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this command)"},
+            "redo_rays_per_launch": round(s2.cast_redo_rays / k, 2),
             "from_profile": profile,
             "reference_equivalent_bytes_per_launch": int(ref_bytes)}
 

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libgmupt.so")
 
-DEVICE_SOURCES = ["csrc/pt_kernels.hip", "csrc/pt_traverse.hip", "csrc/pt_traverse_variants.hip", "csrc/gmupt_capi.hip"]   # pt_traverse_variants.hip is empty without -DGMUPT_VARIANTS
+DEVICE_SOURCES = ["csrc/pt_kernels.hip", "csrc/pt_traverse.hip", "csrc/pt_traverse_wide.hip", "csrc/pt_traverse_variants.hip", "csrc/gmupt_capi.hip"]   # pt_traverse_variants.hip is empty without -DGMUPT_VARIANTS
 HOST_SOURCES = ["host/sbvh_builder.cpp", "host/Camera.cpp", "host/TextureLoader.cpp"]
 HEADERS = ["csrc/pt_traverse_common.hpp", "csrc/pt_traverse_deferred.hpp", "csrc/pt_kernel_util.hpp", "host/MeshData.hpp", "host/BVHWrapper.hpp", "csrc/pt_device.hpp", "csrc/detmath.hpp", "host/sbvh_builder.hpp", "host/Camera.hpp", "host/TextureLoader.hpp", "host/png_reader.hpp", "host/Constants.hpp", "../include/gmupt.h"]
 
@@ -22,8 +22,10 @@ FLAGS = [
 
 
 # Test-only builds of the same sources (tests/test_parity_gpu.py): the traversal ladder kept for A/B timing, and a build whose
-# two-level rank computation has one block per group (so that a small pool reaches the many-group paths of k_logic / k_material).
-TEST_BUILDS = {"variants": ["-DGMUPT_VARIANTS"], "scan1": ["-DGMUPT_SCAN_GROUP=1"]}
+# two-level rank computation has one block per group (so that a small pool reaches the many-group paths of k_logic / k_material),
+# and a build of the wide ray cast whose stacks overflow on ordinary scenes.
+TEST_BUILDS = {"variants": ["-DGMUPT_VARIANTS"], "scan1": ["-DGMUPT_SCAN_GROUP=1"],
+               "wides8": ["-DGMUPT_WIDE_STACK=8", "-DGMUPT_WIDE_TOP=64", "-DGMUPT_WIDE_PARK=4"]}   # wide ray cast with a tiny LDS share per lane: stacks run full, rays are parked for the exact walk all the time
 EXPERIMENT_BUILDS = {}   # name -> extra flags of A/B timing builds (tools/ only, never loaded by tests), e.g. {"wg1024": ["-DGMUPT_DEF_BLOCK=1024", "-DGMUPT_TOP_NODES=512"]}
 
 

@@ -47,7 +47,7 @@ class RendererDesc(C.Structure):
                 ("path_budget", C.c_uint32), ("max_depth", C.c_uint32), ("collect_stats", C.c_uint32)]
 
 
-STAT_STACK_OVERFLOW, STAT_FUSED_CAST, STAT_CAST_FETCH, STAT_STACK_SPILL, STAT_CAST_ABORTED = 1, 2, 4, 8, 16
+STAT_STACK_OVERFLOW, STAT_FUSED_CAST, STAT_CAST_FETCH, STAT_STACK_SPILL, STAT_CAST_ABORTED, STAT_CAST_WIDE = 1, 2, 4, 8, 16, 32
 
 
 class Stats(C.Structure):
@@ -61,7 +61,8 @@ class Stats(C.Structure):
                 ("lane_census", C.c_uint64 * 4), ("cast_waves", C.c_uint64), ("cast_wave_ticks", C.c_uint64), ("cast_wave_ticks_max", C.c_uint64),
                 ("cast_drain_ticks", C.c_uint64), ("cast_drain_iters", C.c_uint64), ("cast_drain_busy_lanes", C.c_uint64),
                 ("cast_wave_end_hist", C.c_uint64 * 32), ("ray_inner_hist", C.c_uint64 * 32),
-                ("ext_top_inner", C.c_uint64), ("sh_top_inner", C.c_uint64), ("cast_helper_subtrees", C.c_uint64)]
+                ("ext_top_inner", C.c_uint64), ("sh_top_inner", C.c_uint64), ("cast_helper_subtrees", C.c_uint64),
+                ("cast_nested_helpers", C.c_uint64), ("cast_redo_rays", C.c_uint64), ("wide_box_tests", C.c_uint64)]
 
     def as_dict(self):
         return {n: (list(getattr(self, n)) if hasattr(getattr(self, n), "__len__") else getattr(self, n)) for n, _ in self._fields_}
@@ -72,8 +73,13 @@ class SbvhParams(C.Structure):
                 ("min_leaf_size", C.c_int32), ("max_leaf_size", C.c_int32), ("node_cost", C.c_float), ("tri_cost", C.c_float)]
 
 
+ERR_CAST_FAULT = -7
+
+
 class GmuptError(RuntimeError):
-    pass
+    def __init__(self, msg, code=0):
+        super().__init__(msg)
+        self.code = code
 
 
 # every symbol include/gmupt.h declares: name -> (restype, argtypes)
@@ -184,7 +190,7 @@ class use_build:
 
 def _check(rc):
     if rc != 0:
-        raise GmuptError("gmupt error %d: %s" % (rc, lib().gmupt_last_error().decode(errors="replace")))
+        raise GmuptError("gmupt error %d: %s" % (rc, lib().gmupt_last_error().decode(errors="replace")), rc)
 
 
 def _ptr(a):
@@ -386,9 +392,13 @@ class Renderer:
         _check(lib().gmupt_get_counters(self.h, C.byref(out)))
         return np.array(list(out), dtype=np.uint32)
 
-    def stats(self):
+    def stats(self, check=True):
+        """gmupt_get_stats.  A launch that flagged its results as invalid makes the call fail (GMUPT_ERR_CAST_FAULT) although the
+        statistics are filled in: check=False returns them anyway (to look at the flags)."""
         s = Stats()
-        _check(lib().gmupt_get_stats(self.h, C.byref(s)))
+        rc = lib().gmupt_get_stats(self.h, C.byref(s))
+        if rc != ERR_CAST_FAULT or check:
+            _check(rc)
         return s
 
     def reset_stats(self):

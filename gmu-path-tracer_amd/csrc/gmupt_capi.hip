@@ -12,6 +12,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
+#include <string>
+#include <unordered_map>
 #include <mutex>
 #include <new>
 #include <string>
@@ -43,6 +46,7 @@ uint32_t traversal_block_threads();
 uint32_t deferred_block_threads();
 uint32_t traversal_overflow_entries();
 uint32_t traversal_top_capacity(uint32_t maxDepth);
+uint32_t traversal_wide_top_capacity();
 }
 using namespace gmupt;
 
@@ -209,7 +213,7 @@ struct gmupt_renderer {
     double msStage[4] = { 0, 0, 0, 0 }; uint64_t timedIters = 0;
     std::vector<void*> allocs;
     // packed traversal copy of the bound scene
-    void* travNodes = nullptr; void* travTris = nullptr; void* travRecs = nullptr;
+    void* travNodes = nullptr; void* travTris = nullptr; void* travRecs = nullptr; void* travWide = nullptr;
     int travMode = 60; // GMUPT_TRAVERSAL: "cast0" (default) both ray casts in one launch | "def0" separate launches; the other rungs of the ladder exist in -DGMUPT_VARIANTS builds only
     uint32_t castFlags = 0; // GMUPT_STAT_* bits of the ray-cast kernels launched since the last reset
 };
@@ -247,6 +251,7 @@ extern "C" void gmupt_renderer_destroy(gmupt_renderer* r)
     if (r->travNodes) (void)hipFree(r->travNodes);
     if (r->travTris) (void)hipFree(r->travTris);
     if (r->travRecs) (void)hipFree(r->travRecs);
+    if (r->travWide) (void)hipFree(r->travWide);
     if (r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
 }
@@ -265,6 +270,7 @@ static int parse_traversal_mode(const char* tv)
     if (std::strncmp(tv, "def", 3) == 0) return 40 + std::atoi(tv + 3);     // separate deferred-leaf launches
     if (std::strncmp(tv, "pipe", 4) == 0) return 50 + std::atoi(tv + 4);    // three-slot lane pipeline
     if (std::strncmp(tv, "cast", 4) == 0) return 60 + std::atoi(tv + 4);    // cast0 mixed lanes + fused fetches, cast1 extension then shadow per wave, cast2 mixed lanes
+    if (std::strcmp(tv, "wide") == 0) return 70;                            // both ray casts in one launch over the 4-wide collapse of the tree (pt_traverse_wide.hip)
     return kDefault;
 }
 
@@ -304,7 +310,7 @@ extern "C" int gmupt_renderer_create(gmupt_device* dev, const gmupt_renderer_des
     { const char* ep = std::getenv("GMUPT_EXTEND_PRUNE"); p.extendPrune = ep ? (uint32_t)std::atoi(ep) : 0u; }
     { const char* sp = std::getenv("GMUPT_SHADOW_PRUNE"); p.shadowPrune = sp ? (uint32_t)std::atoi(sp) : 0u; }
     { const char* lc = std::getenv("GMUPT_CAST_LOOP_CAP"); p.castLoopCap = lc ? (uint32_t)std::atoi(lc) : (1u << 20); if (p.castLoopCap == 0) p.castLoopCap = 1u << 20; }
-    { const char* e1 = std::getenv("GMUPT_REFILL"); p.tuneRefill = e1 ? (uint32_t)std::atoi(e1) : 20u; const char* e2 = std::getenv("GMUPT_TRI_THRESH"); p.tuneTriThresh = e2 ? (uint32_t)std::atoi(e2) : ((r->travMode == 60 || r->travMode == 63) ? 24u : 32u); } // fused fetches make a burst cheaper
+    { const char* e1 = std::getenv("GMUPT_REFILL"); p.tuneRefill = e1 ? (uint32_t)std::atoi(e1) : 20u; const char* e2 = std::getenv("GMUPT_TRI_THRESH"); p.tuneTriThresh = e2 ? (uint32_t)std::atoi(e2) : ((r->travMode == 60 || r->travMode == 63 || r->travMode == 70) ? 24u : 32u); } // fused fetches make a burst cheaper
 
     int rc = GMUPT_OK;
     // Renderer::createBuffers creates the UAV buffers without initial data: D3D11 zero-initialises them
@@ -460,6 +466,131 @@ static int build_traversal_copy(gmupt_renderer* r, const gmupt_buffer* nodesB, c
         if (nodes[i].isLeaf && nodes[i].right > nodes[i].left) std::memcpy(&ptris[(size_t)nodes[i].right - 1].r2[1], &one, 4);
     std::memcpy(&ptris[R].r2[1], &one, 4); // sentinel: all-zero triangle (det = 0, rejected), last flag set
 
+    // word 10 of a triangle record: the number of the first reference with the same (v0, v1, v2, material) -- duplicated references of one
+    // triangle (spatial splits) produce identical hit records, so a tie in t between them is no tie (pt_traverse_wide.hip)
+    const bool wantWide = r->travMode == 70;
+    if (wantWide) {
+        struct Key { int32_t v[3]; uint32_t mat; uint32_t idx; };
+        std::vector<Key> keys(R);
+        for (size_t i = 0; i < R; i++) keys[i] = { { tris[i].v[0], tris[i].v[1], tris[i].v[2] }, tris[i].materialID, (uint32_t)i };
+        std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
+            if (a.v[0] != b.v[0]) return a.v[0] < b.v[0];
+            if (a.v[1] != b.v[1]) return a.v[1] < b.v[1];
+            if (a.v[2] != b.v[2]) return a.v[2] < b.v[2];
+            if (a.mat != b.mat) return a.mat < b.mat;
+            return a.idx < b.idx; });
+        for (size_t i = 0; i < R;) {
+            size_t j = i;
+            while (j < R && keys[j].v[0] == keys[i].v[0] && keys[j].v[1] == keys[i].v[1] && keys[j].v[2] == keys[i].v[2] && keys[j].mat == keys[i].mat) {
+                std::memcpy(&ptris[keys[j].idx].r2[2], &keys[i].idx, 4);
+                j++;
+            }
+            i = j;
+        }
+        const uint32_t none = 0xFFFFFFFFu;
+        std::memcpy(&ptris[R].r2[2], &none, 4);
+    }
+
+    // 4-wide collapse (WNode, pt_device.hpp): the two children of an inner node, the inner one with the largest surface area replaced by
+    // ITS children until four slots are taken; every inner slot becomes a wide node in turn.  Only built when every child box lies inside
+    // its parent's box (what a bounding-volume hierarchy is; the wide walk's equivalence to the binary one rests on it).
+    std::vector<WNode> wide;
+    uint32_t wideTop = 0, wideBound = 0;
+    bool contained = true;
+    for (size_t i = 0; i < N && contained && wantWide; i++) {
+        if (nodes[i].isLeaf) continue;
+        for (int32_t c : { nodes[i].left, nodes[i].right })
+            for (int k = 0; k < 3; k++)
+                if (!(nodes[(size_t)c].min[k] >= nodes[i].min[k] && nodes[(size_t)c].max[k] <= nodes[i].max[k] && nodes[(size_t)c].min[k] <= nodes[(size_t)c].max[k])) contained = false;
+    }
+    if (wantWide && contained && !nodes[0].isLeaf) {
+        auto area = [&](int32_t i) { const gmupt_bvh_node& n = nodes[(size_t)i]; const double dx = (double)n.max[0] - n.min[0], dy = (double)n.max[1] - n.min[1], dz = (double)n.max[2] - n.min[2]; return dx * dy + dy * dz + dz * dx; };
+        // Opening a slot drops ITS box test for the rays that reach its children.  "Child hit implies parent hit" holds for every ray
+        // unless a child is flat on an axis on which the parent is not, in the plane of one of the parent's faces (a ray with d = 0 on that
+        // axis that starts in this plane gets NaNs from the child's two planes -- no condition -- and +-inf from the parent's: a miss;
+        // pt_traverse_wide.hip).  Such a node keeps its own slot.
+        auto opens = [&](int32_t c) {
+            const gmupt_bvh_node& pn = nodes[(size_t)c];
+            for (int32_t x : { pn.left, pn.right }) {
+                const gmupt_bvh_node& cn = nodes[(size_t)x];
+                for (int k = 0; k < 3; k++)
+                    if (cn.min[k] == cn.max[k] && pn.min[k] != pn.max[k] && (cn.min[k] == pn.min[k] || cn.max[k] == pn.max[k])) return false;
+            }
+            return true;
+        };
+        struct Slots { int32_t s[4]; int n; int32_t bin; };
+        std::vector<Slots> created;                    // creation order: parents before children
+        std::vector<int32_t> createdOf(N, -1);
+        std::vector<int32_t> todo{ 0 };
+        while (!todo.empty()) {
+            const int32_t v = todo.back(); todo.pop_back();
+            Slots w; w.bin = v; w.n = 2; w.s[0] = nodes[(size_t)v].left; w.s[1] = nodes[(size_t)v].right; w.s[2] = w.s[3] = -1;
+            while (w.n < 4) {
+                int best = -1;
+                for (int k = 0; k < w.n; k++) if (!nodes[(size_t)w.s[k]].isLeaf && opens(w.s[k]) && (best < 0 || area(w.s[k]) > area(w.s[best]))) best = k;
+                if (best < 0) break;
+                const int32_t c = w.s[best];
+                for (int k = w.n; k > best + 1; k--) w.s[k] = w.s[k - 1];
+                w.s[best] = nodes[(size_t)c].left; w.s[best + 1] = nodes[(size_t)c].right; w.n++;
+            }
+            createdOf[(size_t)v] = (int32_t)created.size();
+            created.push_back(w);
+            for (int k = w.n - 1; k >= 0; k--) if (!nodes[(size_t)w.s[k]].isLeaf) todo.push_back(w.s[k]);
+        }
+        const size_t W = created.size();
+        // numbering: the LDS-resident top first (grown from the root, largest surface area first), then creation order (depth-first)
+        std::vector<int32_t> number(W, -1);
+        int32_t nextW = 0;
+        {
+            std::vector<std::pair<double, int32_t>> frontier{ { area(0), 0 } };
+            const size_t cap = traversal_wide_top_capacity();
+            while (!frontier.empty() && (size_t)nextW < cap) {
+                size_t best = 0;
+                for (size_t k = 1; k < frontier.size(); k++) if (frontier[k].first > frontier[best].first || (frontier[k].first == frontier[best].first && frontier[k].second < frontier[best].second)) best = k;
+                const int32_t c = frontier[best].second;
+                frontier.erase(frontier.begin() + (long)best);
+                number[(size_t)c] = nextW++;
+                const Slots& w = created[(size_t)c];
+                for (int k = 0; k < w.n; k++) if (!nodes[(size_t)w.s[k]].isLeaf) frontier.push_back({ area(w.s[k]), createdOf[(size_t)w.s[k]] });
+            }
+            wideTop = (uint32_t)nextW;
+        }
+        for (size_t c = 0; c < W; c++) if (number[c] < 0) number[c] = nextW++;
+        wide.resize(W);
+        const float qnan = std::numeric_limits<float>::quiet_NaN();
+        for (size_t c = 0; c < W; c++) {
+            const Slots& w = created[c];
+            WNode& o = wide[(size_t)number[c]];
+            for (int k = 0; k < 4; k++) {
+                if (k < w.n) {
+                    const gmupt_bvh_node& b = nodes[(size_t)w.s[k]];
+                    for (int a = 0; a < 3; a++) { o.p[a][k] = b.min[a]; o.p[3 + a][k] = b.max[a]; }
+                    o.link[k] = b.isLeaf ? desc(w.s[k]) : number[(size_t)createdOf[(size_t)w.s[k]]];
+                } else {
+                    for (int a = 0; a < 6; a++) o.p[a][k] = qnan;      // never hit
+                    o.link[k] = (int32_t)0x80000000;
+                }
+            }
+            o.aux[0] = depth[(size_t)w.bin]; o.aux[1] = w.n; o.aux[2] = o.aux[3] = 0;
+        }
+        // most entries the inner stack of a walk can hold: every inner slot hit on every level, the deepest child visited last
+        std::vector<uint32_t> occ(W, 0);
+        for (size_t c = W; c-- > 0;) {
+            const Slots& w = created[c];
+            uint32_t inner = 0, deepest = 0;
+            for (int k = 0; k < w.n; k++) if (!nodes[(size_t)w.s[k]].isLeaf) { inner++; deepest = std::max(deepest, occ[(size_t)createdOf[(size_t)w.s[k]]]); }
+            occ[c] = inner ? inner - 1 + deepest : 0;
+        }
+        wideBound = occ[0];
+    }
+    if (r->travWide) { HIP_TRY(hipFree(r->travWide)); r->travWide = nullptr; }
+    if (!wide.empty()) {
+        HIP_TRY(hipMalloc(&r->travWide, wide.size() * sizeof(WNode)));
+        HIP_TRY(hipMemcpy(r->travWide, wide.data(), wide.size() * sizeof(WNode), hipMemcpyHostToDevice));
+    }
+    r->p.trav.wnodes = (const WNode*)r->travWide; r->p.trav.wideCount = (uint32_t)wide.size(); r->p.trav.wideTopCount = wideTop; r->p.trav.wideStackBound = wideBound;
+    r->p.trav.wideRootDesc = 0;
+
     if (r->travNodes) { HIP_TRY(hipFree(r->travNodes)); r->travNodes = nullptr; }
     if (r->travTris) { HIP_TRY(hipFree(r->travTris)); r->travTris = nullptr; }
     HIP_TRY(hipMalloc(&r->travNodes, packed.size() * sizeof(Node64)));
@@ -589,6 +720,17 @@ static int run_iteration(gmupt_renderer* r, bool doShade, bool doExtend, bool do
     return GMUPT_OK;
 }
 
+// After a stream synchronise: did a ray-cast launch flag its own results as invalid (DevStats::stackOverflow, sticky until gmupt_reset_stats)?
+static int check_cast_flags(gmupt_renderer* r, const char* who)
+{
+    uint32_t flags = 0;
+    HIP_TRY(hipMemcpyAsync(&flags, &r->p.stats->stackOverflow, 4, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    if (flags & 2u) return fail(GMUPT_ERR_CAST_FAULT, "%s: a wave of the ray cast left its loop at the iteration limit (GMUPT_STAT_CAST_ABORTED): the frame is invalid", who);
+    if (flags & 1u) return fail(GMUPT_ERR_CAST_FAULT, "%s: a traversal stack overflowed (GMUPT_STAT_STACK_OVERFLOW): the frame is invalid", who);
+    return GMUPT_OK;
+}
+
 extern "C" int gmupt_iterate(gmupt_renderer* r)
 {
     if (!r) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_iterate: null renderer");
@@ -614,7 +756,7 @@ extern "C" int gmupt_synchronize(gmupt_renderer* r)
     if (!r) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_synchronize: null renderer");
     HIP_TRY(hipSetDevice(r->dev->id));
     HIP_TRY(hipStreamSynchronize(r->stream));
-    return GMUPT_OK;
+    return check_cast_flags(r, "gmupt_synchronize");
 }
 
 extern "C" int gmupt_resize(gmupt_renderer* r, uint32_t width, uint32_t height)
@@ -646,7 +788,7 @@ extern "C" int gmupt_read_framebuffer(gmupt_renderer* r, float* rgba, size_t byt
     HIP_TRY(hipSetDevice(r->dev->id));
     HIP_TRY(hipMemcpyAsync(rgba, r->p.fb, need, hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
-    return GMUPT_OK;
+    return check_cast_flags(r, "gmupt_read_framebuffer");
 }
 
 extern "C" int gmupt_copy_framebuffer_to_device(gmupt_renderer* r, void* device_dst, size_t bytes)
@@ -657,7 +799,7 @@ extern "C" int gmupt_copy_framebuffer_to_device(gmupt_renderer* r, void* device_
     HIP_TRY(hipSetDevice(r->dev->id));
     HIP_TRY(hipMemcpyAsync(device_dst, r->p.fb, need, hipMemcpyDeviceToDevice, r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
-    return GMUPT_OK;
+    return check_cast_flags(r, "gmupt_copy_framebuffer_to_device");
 }
 
 extern "C" int gmupt_get_counters(gmupt_renderer* r, uint32_t out[8])
@@ -702,7 +844,9 @@ extern "C" int gmupt_get_stats(gmupt_renderer* r, gmupt_stats* out)
     out->cast_waves = ds.castWaves; out->cast_wave_ticks = ds.castWaveClocks; out->cast_wave_ticks_max = ds.castWaveClocksMax;
     out->cast_drain_ticks = ds.castDrainClocks; out->cast_drain_iters = ds.castDrainIters; out->cast_drain_busy_lanes = ds.castDrainBusyLanes;
     out->ext_top_inner = ds.extTopInner; out->sh_top_inner = ds.shTopInner; out->cast_helper_subtrees = ds.castHelperSubtrees;
+    out->cast_nested_helpers = ds.castNestedHelpers; out->cast_redo_rays = ds.castRedoRays; out->wide_box_tests = ds.wideBoxTests;
     out->ext_wave_inner = ds.extWaveInner; out->ext_wave_tris = ds.extWaveTris; out->sh_wave_inner = ds.shWaveInner; out->sh_wave_tris = ds.shWaveTris;
+    if (ds.stackOverflow & 3u) return fail(GMUPT_ERR_CAST_FAULT, "gmupt_get_stats: a ray-cast launch flagged its results as invalid (flags %#x; the statistics are filled in)", out->flags);
     return GMUPT_OK;
 }
 
@@ -731,9 +875,10 @@ extern "C" int gmupt_render_budget(gmupt_renderer* r, gmupt_camera* cam, uint32_
     if (!r || !cam) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_render_budget: null argument");
     if (!r->desc.path_budget) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_render_budget: renderer was created without a path_budget");
     HIP_TRY(hipSetDevice(r->dev->id));
-    uint32_t* hostActive = nullptr;
-    HIP_TRY(hipHostMalloc((void**)&hostActive, 4, hipHostMallocDefault));
-    *hostActive = 1;
+    static_assert(offsetof(DevStats, stackOverflow) == offsetof(DevStats, activePaths) + 4, "the drain check reads both words with one copy");
+    uint32_t* hostActive = nullptr;   // [0] activePaths, [1] stackOverflow
+    HIP_TRY(hipHostMalloc((void**)&hostActive, 8, hipHostMallocDefault));
+    hostActive[0] = 1; hostActive[1] = 0;
     uint32_t k = 0;
     int rc = GMUPT_OK;
     // Drain: stop when no slot is active any more -- or kDrainHorizon iterations after the budget ran out.  A healthy path lives at most
@@ -750,9 +895,10 @@ extern "C" int gmupt_render_budget(gmupt_renderer* r, gmupt_camera* cam, uint32_
         if (rc == GMUPT_OK) rc = gmupt_iterate(r);   // Renderer::draw
         if (rc != GMUPT_OK) break;
         if ((k & 7u) == 7u) {                        // drain check without stalling every iteration
-            hipError_t e = hipMemcpyAsync(hostActive, &r->p.stats->activePaths, 4, hipMemcpyDeviceToHost, r->stream);
+            hipError_t e = hipMemcpyAsync(hostActive, &r->p.stats->activePaths, 8, hipMemcpyDeviceToHost, r->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
             if (e != hipSuccess) { rc = fail(GMUPT_ERR_HIP, "gmupt_render_budget: %s", hipGetErrorString(e)); break; }
+            if (hostActive[1] & 3u) { rc = fail(GMUPT_ERR_CAST_FAULT, "gmupt_render_budget: a ray-cast launch flagged its results as invalid after %u iterations (flags %#x)", k + 1, hostActive[1]); k++; break; }
             if (*hostActive == 0) { k++; break; }
             if (*hostActive < r->p.L && drainStart == 0xFFFFFFFFu) drainStart = k;     // the first slots have retired: the budget is spent
             if (drainStart != 0xFFFFFFFFu && k - drainStart >= kDrainHorizon) { k++; break; }
@@ -760,6 +906,7 @@ extern "C" int gmupt_render_budget(gmupt_renderer* r, gmupt_camera* cam, uint32_
     }
     (void)hipHostFree(hostActive);
     if (rc == GMUPT_OK) { hipError_t e = hipStreamSynchronize(r->stream); if (e != hipSuccess) rc = fail(GMUPT_ERR_HIP, "gmupt_render_budget: %s", hipGetErrorString(e)); }
+    if (rc == GMUPT_OK) rc = check_cast_flags(r, "gmupt_render_budget");
     if (iters) *iters = k;
     return rc;
 }

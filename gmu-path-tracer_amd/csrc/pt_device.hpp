@@ -61,6 +61,9 @@ struct DevStats {
     unsigned long long rayInnerHist[32];    // extension rays by inner nodes visited, 16 per bucket
     unsigned long long extTopInner, shTopInner; // inner-node visits served by the LDS-resident top of the tree (no vector-memory request)
     unsigned long long castHelperSubtrees;      // subtrees handed to idle lanes in the drain of the fused ray cast
+    unsigned long long castNestedHelpers;       // of those: subtrees a HELPER gave away in turn (collect_stats)
+    unsigned long long castRedoRays;            // wide ray cast: rays walked again in the reference's binary order (closest hit an exact tie between two triangles; a full stack)
+    unsigned long long wideBoxTests;            // wide ray cast, collect_stats: occupied box slots tested
     uint32_t activePaths;
     uint32_t stackOverflow; // bit 0: traversal needed more than the provisioned stack (results then differ from an unbounded stack); bit 1: a wave of the fused ray cast left at its iteration limit
 };
@@ -91,6 +94,16 @@ struct alignas(64) Node64 { float a[4], b[4], c[4]; int32_t d[4]; };
 struct alignas(16) Tri48 { float r0[4], r1[4], r2[4]; };
 static_assert(sizeof(Node64) == 64 && sizeof(Tri48) == 48, "packed traversal records");
 
+// WNode: one node of the 4-wide collapse of the binary tree (pt_traverse_wide.hip) -- exactly one 128-byte line, the unit of every
+// memory-side read of this chip.  Up to four descendants of one inner node of the binary tree (its two children, the inner ones among
+// them replaced by THEIR children, largest surface area first, until four slots are taken), plane by plane so that the four slab tests
+// of a step are 4-wide vector arithmetic:
+//   p[0] = min.x of slots 0..3   p[1] = min.y   p[2] = min.z   p[3] = max.x   p[4] = max.y   p[5] = max.z   (an empty slot is all NaN: never hit)
+//   link[k] >= 0: index of the WNode of that descendant; < 0: leaf whose first triangle record is ~link[k]; kDone in an empty slot
+//   aux[0] = depth of the node in the binary tree, aux[1] = number of occupied slots
+struct alignas(128) WNode { float p[6][4]; int32_t link[4]; int32_t aux[4]; };
+static_assert(sizeof(WNode) == 128, "one wide node per 128-byte line");
+
 // Rec64: the same data as 64-byte records in ONE array (inner nodes first, then one record per triangle reference) for the
 // cooperative ray-cast kernels: a lane needs exactly one record per step, and four adjacent lanes fetch the four 16-byte
 // quarters of one record with a single LDS-DMA instruction.  Triangle record: r0..r2 as Tri48, r3 = (v0, v1, v2, materialID).
@@ -115,6 +128,12 @@ struct TravScene {
     uint32_t topCountDeep; // the same for the layout of the spilling-stack instantiations (topCountDeep >= topCount: one numbering serves both)
     uint32_t maxDepth;     // depth of the deepest node (bounds the traversal stack)
     float rootMin[3], rootMax[3];
+    // 4-wide collapse of the same tree (pt_traverse_wide.hip)
+    const WNode* wnodes;
+    uint32_t wideCount;      // records of wnodes
+    uint32_t wideTopCount;   // wnodes[0 .. wideTopCount) live in LDS (largest surface area first)
+    uint32_t wideStackBound; // entries the walk of this tree can have pending at most (all four slots hit on every level)
+    int32_t wideRootDesc;    // 0 (the root's WNode) or the leaf descriptor of a one-leaf tree
 };
 
 struct RenderParams {

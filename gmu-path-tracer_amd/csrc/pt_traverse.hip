@@ -540,15 +540,22 @@ bool traversal_mode_available(int mode)
 #ifdef GMUPT_VARIANTS
     (void)mode; return true;
 #else
-    return mode == 60 || mode == 40;
+    return mode == 60 || mode == 40 || mode == 70;
 #endif
 }
 
 // Both ray casts in one launch.  Returns the GMUPT_STAT_* bits of what was launched, or 0 when the fused kernel does not take this
 // configuration (opt-in prunings; node / triangle arrays beyond the 32-bit offsets of its buffer resources): the caller then runs the
 // two separate launches (launch_extend + launch_shadow).
+uint32_t launch_cast_wide(const RenderParams& p, bool stats, hipStream_t s);   // pt_traverse_wide.hip
+
 uint32_t launch_cast(const RenderParams& p, bool stats, int mode, hipStream_t s)
 {
+    if (mode == 70) {   // wide: the 4-wide collapse; a configuration it does not take (no collapse built, opt-in prunings) runs the default kernel
+        const uint32_t launched = launch_cast_wide(p, stats, s);
+        if (launched) return launched;
+        mode = 60;
+    }
     const uint32_t pb = p.travGridBlocks;
     const bool ovf = p.trav.maxDepth + 2 > (uint32_t)kDefStack;
     const bool plain = !p.extendPrune && !p.shadowPrune;   // the opt-in prunings exist in the separate bodies only
@@ -610,9 +617,11 @@ uint32_t traversal_block_threads() { return kTravBlock; }
 uint32_t deferred_block_threads() { return kDefBlock; }
 // nodes of the tree top the ray casts of a tree of this depth keep in LDS (the spilling-stack instantiations hold more, see kDefLdsTop)
 uint32_t traversal_top_capacity(uint32_t maxDepth) { return maxDepth + 2 > (uint32_t)kDefStack ? (uint32_t)kDeepTopTreeNodes : (uint32_t)kTopTreeNodes; }
+uint32_t traversal_wide_overflow_entries();   // pt_traverse_wide.hip
 uint32_t traversal_overflow_entries()
 {
     uint32_t a = (uint32_t)(kMaxStack + 1 - kDeepStack);
+    if (traversal_wide_overflow_entries() > a) a = traversal_wide_overflow_entries();
 #ifdef GMUPT_VARIANTS
     const uint32_t b = variant_overflow_entries(); if (b > a) a = b;
 #endif

@@ -51,7 +51,7 @@ struct DefStack {
     {
         if (!OVF || ptr < kDefLdsStack<OVF>) lds[ptr * kDefBlock] = v;
         else if (ptr < kMaxStack + 1) ovf[(size_t)(ptr - kDefLdsStack<OVF>) * ovfStride] = v;
-        else st->stackOverflow = 1u;
+        else atomicOr(&st->stackOverflow, 1u);   // (bit 1 is the watchdog's: a plain store would erase it)
         ptr++;
     }
     __device__ __forceinline__ int pop()

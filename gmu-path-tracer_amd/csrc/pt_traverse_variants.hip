@@ -40,7 +40,7 @@ struct TravStack {
     {
         if (ptr < kLdsStack) lds[ptr * kTravBlock] = v;
         else if (ptr < kMaxStack) ovf[(size_t)(ptr - kLdsStack) * ovfStride] = v;
-        else st->stackOverflow = 1u;
+        else atomicOr(&st->stackOverflow, 1u);
         ptr++;
     }
     __device__ __forceinline__ int pop()
@@ -248,7 +248,7 @@ struct PackedStack {
     {
         if (ptr < kLdsStack) lds[ptr * kTravBlock] = v;
         else if (ptr < kMaxStack) ovf[(size_t)(ptr - kLdsStack) * ovfStride] = v;
-        else st->stackOverflow = 1u;
+        else atomicOr(&st->stackOverflow, 1u);
         ptr++;
     }
     __device__ __forceinline__ int pop()
@@ -845,7 +845,7 @@ struct TopStack {
     {
         if (ptr < kTopStack) lds[ptr * kTravBlock] = v;
         else if (ptr < kMaxStack) ovf[(size_t)(ptr - kTopStack) * ovfStride] = v;
-        else st->stackOverflow = 1u;
+        else atomicOr(&st->stackOverflow, 1u);
         ptr++;
     }
     __device__ __forceinline__ int pop()
@@ -1082,7 +1082,7 @@ struct CoopStack {
     {
         if (ptr < kCoopStack) lds[ptr * kCoopBlock] = v;
         else if (ptr < kMaxStack) ovf[(size_t)(ptr - kCoopStack) * ovfStride] = v;
-        else st->stackOverflow = 1u;
+        else atomicOr(&st->stackOverflow, 1u);
         ptr++;
     }
     __device__ __forceinline__ int pop()

@@ -1,0 +1,427 @@
+// Wide ray cast for gfx950 (MI355X): both ray casts in one persistent launch over a 4-WIDE collapse of the binary SBVH, one 128-byte
+// record -- one memory-side line -- per dependent step (GMUPT_TRAVERSAL=wide).
+//
+// Why the walk may be restructured at all.  The reference never prunes a box against the current hit: a child is visited iff its slab
+// test returns > 0 (extensionRayCast.hlsl:79-94,132-159).  So the set of leaves a ray reaches is fixed -- every leaf whose box and all of
+// whose ancestors' boxes are hit -- and so are the triangle tests.  A child's box lies inside its parent's box and the slab arithmetic
+// is monotone in the plane coordinates (binary32 subtraction and multiplication by the same 1 / d are monotone; NaN-dropping min / max
+// keep the child's interval inside the parent's), so "child hit" implies "parent hit" and testing only SOME of a leaf's ancestors
+// reaches exactly the same leaves.  Two conditions, both checked on the host when the collapse is built (gmupt_capi.hip):
+//   - every child box lies inside its parent's box (a tree that violates it is walked by the binary kernel);
+//   - the one case where monotonicity fails: a ray with an infinite 1 / d component (d = 0 on an axis; the reference's 8-bit random
+//     numbers make 0.3 % of the bounces off axis-aligned walls such rays) whose origin lies exactly in the plane of a box that is FLAT
+//     on that axis.  0 x inf = NaN is dropped by min / max, so the flat box imposes no condition, while a non-flat parent that has
+//     this plane as a FACE is missed (near = far = +-inf).  An inner node with a child that is flat on one of its faces is therefore
+//     never opened by the collapse: its own box test is kept, exactly where the reference makes it.
+// What the visit ORDER decides is only which of two accepted hits with bitwise equal t wins (`t < distance` is strict,
+// extensionRayCast.hlsl:64-74).  This kernel walks in whatever order is cheapest, notices when the closest hit of an extension ray is
+// such a tie between two DIFFERENT triangles (the duplicated references of one triangle give identical hit records either way) and
+// then PARKS the ray in its lane; parked rays are walked again in the reference's binary near-first order on the packed binary copy
+// (Node64), all parked lanes of the wave at once -- at the end of the wave's life, or as soon as a quarter of its lanes are parked.
+// A handful of rays per launch on ordinary scenes, most rays on the adversarial grid meshes of the tests.  A shadow ray is any-hit:
+// its result does not depend on the order at all (shadowRayCast.hlsl:88-91).
+//
+// Per lane: ONE array of kWideStack words in LDS ([entry][lane], conflict-free) holds two stacks growing towards each other -- inner
+// nodes still to visit from the bottom up, leaves still to test from the top down.  A step fetches one WNode (seven 16-byte pieces:
+// six planes x four slots, four links), does the four slab tests, keeps one hit inner slot as the next node and pushes the other
+// hits.  Leaves are tested in wave-wide bursts, one triangle record per step, fetched together with the node of the walking lanes
+// (as k_cast_f).  A lane whose inner stack alone fills its LDS share gives the wide walk of that ray up and parks it as well (the exact
+// walk has a bounds-checked global overflow).  Drain: finished lanes take the BOTTOM inner entry of busy lanes (the largest subtree
+// left) and report their best hit back; results merge by "smaller t wins, equal t is a tie".
+#include "pt_traverse_deferred.hpp"
+
+namespace gmupt {
+
+#ifndef GMUPT_WIDE_STACK
+#define GMUPT_WIDE_STACK 28
+#endif
+#ifndef GMUPT_WIDE_TOP
+#define GMUPT_WIDE_TOP 384
+#endif
+#ifndef GMUPT_WIDE_REPS
+#define GMUPT_WIDE_REPS 4
+#endif
+#ifndef GMUPT_WIDE_PARK
+#define GMUPT_WIDE_PARK 16
+#endif
+constexpr int kWideStack = GMUPT_WIDE_STACK;   // LDS words per lane shared by the two stacks
+constexpr int kWideTop = GMUPT_WIDE_TOP;       // WNodes of the tree top kept in LDS
+constexpr int kWideRoom = 4;                   // a node step pushes at most four entries
+constexpr int kWidePark = GMUPT_WIDE_PARK;     // parked lanes of a wave that trigger the exact walk before the wave has run dry
+static_assert(kWideStack * kDefBlock * 4 + kWideTop * 128 <= 160 * 1024, "LDS of one CU (wide layout)");
+constexpr int kWideOvf = kMaxStack + 2 > kWideStack ? kMaxStack + 2 - kWideStack : 0;   // the exact walk's stack: the lane's LDS share, then this many entries of the global overflow buffer
+
+typedef int vec4i __attribute__((ext_vector_type(4)));
+
+// One WNode into registers: the LDS lanes first, then the global lanes (see load_node in pt_traverse_deferred.hpp)
+__device__ __forceinline__ void load_wnode(__amdgpu_buffer_rsrc_t nodes, const float4* s_top, uint32_t topCount, int cur,
+                                           vec4f& q0, vec4f& q1, vec4f& q2, vec4f& q3, vec4f& q4, vec4f& q5, vec4i& lk)
+{
+    const bool inTop = (uint32_t)cur < topCount;
+    if (inTop) {
+        const GMUPT_AS_LDS vec4f* n = (const GMUPT_AS_LDS vec4f*)(s_top) + cur * 8;
+        q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = n[3]; q4 = n[4]; q5 = n[5]; lk = *(const GMUPT_AS_LDS vec4i*)(n + 6);
+    }
+    asm volatile("" ::: "memory");
+    if (!inTop) {
+        const int off = cur * 128;
+        q0 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off, 0, 0));
+        q1 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 16, 0, 0));
+        q2 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 32, 0, 0));
+        q3 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 48, 0, 0));
+        q4 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 64, 0, 0));
+        q5 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 80, 0, 0));
+        lk = __builtin_bit_cast(vec4i, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 96, 0, 0));
+    }
+}
+
+// the slab test of ray_box (extensionRayCast.hlsl:79-94) on one slot; "hit" is `result > 0`, i.e. t1 >= t0 and (t0 > 0 ? t0 : t1) > 0,
+// which is t1 >= t0 && t1 > 0 (t1 >= t0 > 0 implies t1 > 0; a NaN fails both forms)
+__device__ __forceinline__ bool slab_hit(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, f3 o, f3 invdir)
+{
+    const float fx = (mxx - o.x) * invdir.x, fy = (mxy - o.y) * invdir.y, fz = (mxz - o.z) * invdir.z;
+    const float nx = (mnx - o.x) * invdir.x, ny = (mny - o.y) * invdir.y, nz = (mnz - o.z) * invdir.z;
+    const float t1 = __builtin_fminf(__builtin_fmaxf(fx, nx), __builtin_fminf(__builtin_fmaxf(fy, ny), __builtin_fmaxf(fz, nz)));
+    const float t0 = __builtin_fmaxf(__builtin_fminf(fx, nx), __builtin_fmaxf(__builtin_fminf(fy, ny), __builtin_fminf(fz, nz)));
+    return (t1 >= t0) & (t1 > 0.0f);
+}
+
+// source-triangle number of a reference (word 10 of its Tri48 record): equal for the duplicated references of one triangle
+__device__ __forceinline__ uint32_t tri_canon(__amdgpu_buffer_rsrc_t tris, int i)
+{
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(tris, i * 48 + 40, 0, 0);
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
+{
+    constexpr int S = kWideStack;
+    constexpr int REPS = GMUPT_WIDE_REPS;
+    __shared__ int s_stack[S * kDefBlock];
+    __shared__ float4 s_top[kWideTop * 8];
+    {
+        const float4* src = reinterpret_cast<const float4*>(p.trav.wnodes);
+        for (uint32_t k = threadIdx.x; k < p.trav.wideTopCount * 8u; k += kDefBlock) s_top[k] = src[k];
+        __syncthreads();
+    }
+    shadow_counter_epilogue(p);
+    int* sl = s_stack + threadIdx.x;     // entry i of this lane: sl[i * kDefBlock]
+    TravCount tcE = { 0, 0, 0 }, tcS = { 0, 0, 0 }; uint32_t raysE = 0, raysS = 0, wInE = 0, wTrE = 0, wInS = 0, wTrS = 0;
+    const TravScene& ts = p.trav;
+    const uint32_t countExt = p.qc[QC_EXT_COUNT], countSh = p.qc[QC_SHADOWRAY];  // extensionRayCast.hlsl:205, shadowRayCast.hlsl:151
+    const uint32_t* qExt = p.queues + (size_t)Q_EXT_RAY * p.P;
+    const uint32_t* qSh = p.queues + (size_t)Q_SHADOW_RAY * p.P;
+    const __amdgpu_buffer_rsrc_t rNodes = make_rsrc(ts.wnodes, ts.wideCount * 128u);
+    const __amdgpu_buffer_rsrc_t rTris = make_rsrc(ts.tris, (p.scene.numTris + 1u) * 48u);    // + the sentinel record
+    const uint32_t topCount = ts.wideTopCount;
+    uint32_t next = 0, end = 0, lastBase = 0;
+    uint32_t chunkBase = 0, qe0 = kQueueHole, qe1 = kQueueHole;  // the current chunk of queue entries, lane l holds entries l and 64 + l
+    int phase = 0;
+    uint32_t census0 = 0, census1 = 0, census2 = 0, census3 = 0, topE = 0, topS = 0, helped = 0, nested = 0, boxes = 0;
+
+    bool haveRay = false;
+    int kind = 0;                 // 0: extension ray, 1: shadow ray; 2 / 3: the same, PARKED for the exact walk
+    uint32_t index = 0;
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), invdir = mk3(0, 0, 0);
+    float distance = kFltMax;     // extension: closest hit so far; shadow: distance of the light
+    float hu = 0.0f, hv = 0.0f;
+    int hitRef = -1;              // extension: triangle record of the closest hit; shadow: >= 0 when occluded
+    bool redo = false;            // the wide walk does not decide this ray: its closest hit ties with a hit of another triangle, or a stack ran full
+    int cur = kDone;              // >= 0: WNode to visit; kDone: nothing in hand
+    uint32_t pa = 0;              // inner stack: entries sl[bottom .. pa)
+    uint32_t pb = S - 1;          // leaf stack: entries sl(pb .. S - 1], pushed downwards
+    uint32_t bottom = 0;          // entries below were given to helper lanes
+    int ti = -1;                  // next triangle record of the leaf being tested
+    int owner = -1;               // >= 0: this lane walks a subtree given to it by lane `owner` (same ray)
+    uint32_t outstanding = 0;     // helpers that have not reported yet
+    uint32_t donations = 0;       // subtrees this lane has given away for its current ray
+    float tT = kFltMax, uT = 0.0f, vT = 0.0f; int refT = -1; bool redoT = false;   // best result reported by this lane's helpers so far
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gtid = blockIdx.x * kDefBlock + threadIdx.x;
+
+    // the helpers' results into the lane's own, once all of them have reported (any order: the smaller t wins, equal t between two lanes
+    // counts as a tie; an occluder found by anybody decides a shadow ray whatever else happened)
+#define GMUPT_WIDE_MERGE_OWN() \
+    do { if (kind == 0) { redo = redo || redoT || (refT >= 0 && tT == distance); if (refT >= 0 && tT < distance) { distance = tT; hu = uT; hv = vT; hitRef = refT; } } \
+         else { if (refT >= 0) hitRef = refT; redo = (redo || redoT) && hitRef < 0; } \
+         tT = kFltMax; refT = -1; redoT = false; } while (0)
+    // the end of a decided ray in its lane
+#define GMUPT_WIDE_FINISH() \
+    do { if (kind == 0) finish_extension_ray(p, index, o, d, distance, hu, hv, hitRef);            /* extensionRayCast.hlsl:218-232 */ \
+         else stu(p, F_IN_SHADOW, index, hitRef >= 0 ? 1u : 0u);                                    /* shadowRayCast.hlsl:167 */ \
+         haveRay = false; redo = false; } while (0)
+
+    // Watchdog: a persistent kernel must end whatever happens (see k_cast_f)
+    uint32_t loopCount = 0;
+    for (;;) {
+        if (++loopCount > p.castLoopCap) { if (lane == 0u) atomicOr(&p.stats->stackOverflow, 2u); break; }
+        const bool leavesEmpty = pb == (uint32_t)(S - 1);
+        if (phase == 2) { // wave-uniform: drain service
+            // (a) helpers that have finished their subtree (and have heard from their own helpers) report to their owner
+            const bool reports = haveRay && owner >= 0 && outstanding == 0u && cur == kDone && leavesEmpty && ti < 0;
+            if (reports) GMUPT_WIDE_MERGE_OWN();
+            unsigned long long fin = __ballot(reports);
+            while (fin) {
+                const int hl = __builtin_ctzll(fin); fin &= fin - 1ull;
+                const int ol = __builtin_amdgcn_readlane(owner, hl);
+                const float th = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, distance), hl));
+                const float uh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hu), hl));
+                const float vh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hv), hl));
+                const int rh = __builtin_amdgcn_readlane(hitRef, hl);
+                const int redoh = __builtin_amdgcn_readlane((int)redo, hl);
+                if ((int)lane == ol) {
+                    outstanding--;
+                    redoT = redoT || redoh != 0;
+                    if (rh >= 0) {
+                        if (kind == 1) refT = rh;                                                       // any occluder decides a shadow ray
+                        else if (th < tT) { tT = th; uT = uh; vT = vh; refT = rh; }
+                        else if (th == tT) redoT = true;
+                    }
+                }
+                if ((int)lane == hl) { haveRay = false; owner = -1; tT = kFltMax; refT = -1; redoT = false; redo = false; }
+            }
+        }
+        {   // a lane whose own walk has ended and whose helpers have all reported knows its result -- or that the wide walk did not decide
+            // the ray: then the ray is PARKED in the lane (not idle, not free) until the exact walk below takes it
+            const bool ended = haveRay && kind < 2 && owner < 0 && outstanding == 0u && cur == kDone && leavesEmpty && ti < 0;
+            if (ended) { GMUPT_WIDE_MERGE_OWN(); if (redo) { kind += 2; redo = false; pa = 0; bottom = 0; } }
+        }
+        if (phase == 2) { // wave-uniform: drain service, continued
+            // (b) owners that are done and have heard from all their helpers are written back now: their lanes become free
+            const bool done = haveRay && kind < 2 && owner < 0 && outstanding == 0u && cur == kDone && leavesEmpty && ti < 0;
+            // (a lane whose walk has ended never gives: an occluded shadow ray leaves its stack behind, and those subtrees no longer matter)
+            const unsigned long long wantHelp = __ballot(haveRay && cur != kDone && pa > bottom && donations < 12u);
+            if (wantHelp != 0ull && done) GMUPT_WIDE_FINISH();
+            // (c) free lanes take the bottom inner entry of lanes that still have some: the k-th free lane pairs with the k-th donor
+            const unsigned long long freeLanes = __ballot(!haveRay);
+            if (wantHelp != 0ull && freeLanes != 0ull) {
+                const uint32_t nDonors = (uint32_t)__popcll(wantHelp), nFree = (uint32_t)__popcll(freeLanes);
+                const uint32_t nPairs = nDonors < nFree ? nDonors : nFree;
+                const bool isDonor = ((wantHelp >> lane) & 1ull) != 0ull;
+                const uint32_t dRank = prefix_rank(wantHelp), fRank = prefix_rank(freeLanes);
+                const bool gives = isDonor && dRank < nPairs, takes = !haveRay && fRank < nPairs;
+                int node = 0;
+                if (gives) {
+                    node = sl[bottom * kDefBlock];
+                    bottom++; outstanding++; donations++;
+                    if (STATS) { helped++; if (owner >= 0) nested++; }
+                }
+                const int donorOfRank = __builtin_amdgcn_ds_permute((int)((gives ? dRank : 63u) << 2), gives ? (int)lane : 0);
+                const int src = __shfl(donorOfRank, takes ? (int)fRank : 0);
+                const int srcLane = takes ? src : (int)lane;
+                const int node2 = __shfl(node, srcLane), k2 = __shfl(kind, srcLane), i2 = __shfl((int)index, srcLane);
+                const float ox = __shfl(o.x, srcLane), oy = __shfl(o.y, srcLane), oz = __shfl(o.z, srcLane), dx = __shfl(d.x, srcLane), dy = __shfl(d.y, srcLane), dz = __shfl(d.z, srcLane);
+                const float lim = __shfl(distance, srcLane);
+                if (takes) {
+                    haveRay = true; owner = src; kind = k2; index = (uint32_t)i2; donations = 0;
+                    o = mk3(ox, oy, oz); d = mk3(dx, dy, dz); invdir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    distance = k2 == 1 ? lim : kFltMax;     // shadow: the distance of the light; extension: no hit yet
+                    hitRef = -1; hu = 0.0f; hv = 0.0f; redo = false;
+                    pa = 0; bottom = 0; pb = S - 1; outstanding = 0; ti = -1;
+                    tT = kFltMax; refT = -1; redoT = false;
+                    cur = node2;
+                }
+            }
+        }
+        // (a helper, a lane that still waits for its helpers, or a parked lane is not idle)
+        const bool parked = haveRay && kind >= 2;
+        const bool idle = (cur == kDone) && (pb == (uint32_t)(S - 1)) && (ti < 0) && !(haveRay && (owner >= 0 || outstanding != 0u || kind >= 2));
+        const unsigned long long idleMask = __ballot(idle);
+        const int nIdle = __popcll(idleMask);
+        const unsigned long long parkedMask = __ballot(parked);
+        if (parkedMask != 0ull) {
+            const int nParked = __popcll(parkedMask);
+            if (nParked >= kWidePark || nParked + nIdle == 64) {   // wave-uniform
+                // ---- the exact walk of the parked rays, as the reference walks them: binary tree, nearer child first, the farther one deferred,
+                // triangles of a leaf in order, strict `t < distance` (extensionRayCast.hlsl:96-166); any occluder within the light's distance for a
+                // shadow ray (shadowRayCast.hlsl:65-136).  Packed binary copy (Node64 / Tri48); stack = the lane's LDS share, then the global overflow.
+                if (lane == 0u) atomicAdd(&p.stats->castRedoRays, (unsigned long long)nParked);
+                if (parked) {
+                    const bool shadowRay = kind == 3;
+                    o = shadowRay ? ld3(p, F_SH_OX, index) : ld3(p, F_RAY_OX, index);
+                    d = shadowRay ? ld3(p, F_SH_DX, index) : ld3(p, F_RAY_DX, index);
+                    distance = shadowRay ? ldf(p, F_LIGHT_DIST, index) : kFltMax;
+                    invdir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    hitRef = -1; hu = 0.0f; hv = 0.0f;
+                    int* ovf = p.ovfStack + gtid;
+                    uint32_t sp = 0;
+#define GMUPT_EXACT_PUSH(V) do { if (sp < (uint32_t)S) sl[sp * kDefBlock] = (V); else if (sp - (uint32_t)S < (uint32_t)kWideOvf) ovf[(size_t)(sp - (uint32_t)S) * p.ovfStride] = (V); \
+                                 else atomicOr(&p.stats->stackOverflow, 1u); sp++; } while (0)
+#define GMUPT_EXACT_POP(DST) do { --sp; if (sp < (uint32_t)S) DST = sl[sp * kDefBlock]; else if (sp - (uint32_t)S < (uint32_t)kWideOvf) DST = ovf[(size_t)(sp - (uint32_t)S) * p.ovfStride]; else DST = kDone; } while (0)
+                    GMUPT_EXACT_PUSH(kDone);
+                    int c = (ray_box(ts.rootMin[0], ts.rootMin[1], ts.rootMin[2], ts.rootMax[0], ts.rootMax[1], ts.rootMax[2], o, invdir) > 0.0f) ? ts.rootDesc : kDone;
+                    while (c != kDone) {
+                        if (c >= 0) {
+                            const Node64& nd = ts.nodes[c];
+                            const float leftHit = ray_box(nd.a[0], nd.a[1], nd.a[2], nd.a[3], nd.b[0], nd.b[1], o, invdir);
+                            const float rightHit = ray_box(nd.b[2], nd.b[3], nd.c[0], nd.c[1], nd.c[2], nd.c[3], o, invdir);
+                            const bool l = leftHit > 0.0f, r = rightHit > 0.0f;
+                            const bool swap = leftHit > rightHit;                 // extensionRayCast.hlsl:136
+                            const int dl = nd.d[0], dr = nd.d[1];
+                            if (l && r) { GMUPT_EXACT_PUSH(swap ? dl : dr); c = swap ? dr : dl; }
+                            else if (l | r) c = l ? dl : dr;
+                            else GMUPT_EXACT_POP(c);
+                        } else {
+                            int tix = ~c;
+                            bool decided = false;
+                            for (;;) {
+                                float t = 0.0f, u = 0.0f, v = 0.0f; bool last;
+                                if (tri_test(ts.tris, tix, o, d, t, u, v, last)) {
+                                    if (shadowRay) { if (t > kEpsilon && t < 1.0f / kEpsilon && length3(d * t) < distance) { hitRef = tix; decided = true; break; } }   // shadowRayCast.hlsl:41-45,89
+                                    else if (t >= 0.0f && t < distance) { distance = t; hitRef = tix; hu = u; hv = v; }                                              // extensionRayCast.hlsl:64-74
+                                }
+                                if (last) break;
+                                tix++;
+                            }
+                            if (decided) c = kDone; else GMUPT_EXACT_POP(c);
+                        }
+                    }
+#undef GMUPT_EXACT_PUSH
+#undef GMUPT_EXACT_POP
+                    if (shadowRay) stu(p, F_IN_SHADOW, index, hitRef >= 0 ? 1u : 0u);            // shadowRayCast.hlsl:167
+                    else finish_extension_ray(p, index, o, d, distance, hu, hv, hitRef);         // extensionRayCast.hlsl:218-232
+                    haveRay = false; kind = 0; redo = false; cur = kDone; pa = 0; bottom = 0; pb = S - 1; ti = -1;
+                    tT = kFltMax; refT = -1; redoT = false; hitRef = -1;
+                }
+                continue;
+            }
+        }
+        if (nIdle == 64 || (nIdle >= (int)p.tuneRefill && phase < 2)) { // wave-uniform
+            while (next >= end && phase < 2) { // next chunk of the current queue, or the first one of the next queue
+                uint32_t base = 0;
+                const uint32_t count = phase == 0 ? countExt : countSh;
+                const uint32_t gridWaves = gridDim.x * (uint32_t)(kDefBlock / 64);
+                const bool tail = phase == 1 && lastBase + 2u * gridWaves * p.raysPerWave > count;   // towards the end of the last queue the chunks shrink
+                const uint32_t req = tail ? (p.raysPerWave > 64u ? p.raysPerWave / 2u : p.raysPerWave) : p.raysPerWave;
+                if (lane == 0u) base = atomicAdd(&p.travCounters[phase], req);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (base < count) {
+                    lastBase = base;
+                    next = base; end = (base + req < count) ? base + req : count;
+                    chunkBase = base;
+                    const uint32_t* q = phase == 0 ? qExt : qSh;
+                    qe0 = (base + lane < end) ? q[base + lane] : kQueueHole;
+                    qe1 = (base + 64u + lane < end) ? q[base + 64u + lane] : kQueueHole;
+                }
+                else { phase++; next = end = 0; lastBase = 0; }
+            }
+            const uint32_t my = next + prefix_rank(idleMask);
+            const uint32_t entry = idle ? ((my - chunkBase) & 127u) : 0u;
+            const uint32_t entryLo = (uint32_t)__shfl((int)qe0, (int)(entry & 63u)), entryHi = (uint32_t)__shfl((int)qe1, (int)(entry & 63u));
+            if (idle) {
+                // the next ray first: its loads are in flight while the finished ray is written back
+                const bool take = my < end;
+                const uint32_t newIndex = take ? (entry < 64u ? entryLo : entryHi) : kQueueHole;   // extensionRayCast.hlsl:210 / shadowRayCast.hlsl:159
+                const bool newRay = take && (phase != 0 || newIndex != kQueueHole); // holes only exist in the extension queue
+                f3 newO = mk3(0, 0, 0), newD = mk3(0, 0, 1); float newDist = kFltMax;
+                if (newRay) {
+                    if (phase == 0) { newO = ld3(p, F_RAY_OX, newIndex); newD = ld3(p, F_RAY_DX, newIndex); }                 // :213-214
+                    else { newO = ld3(p, F_SH_OX, newIndex); newD = ld3(p, F_SH_DX, newIndex); newDist = ldf(p, F_LIGHT_DIST, newIndex); } // :162-164
+                }
+                if (haveRay) GMUPT_WIDE_FINISH();   // (decided: a ray that needs the exact walk was parked at the top of the loop and its lane is not idle)
+                if (newRay) {
+                    bottom = 0; donations = 0;
+                    haveRay = true; kind = phase; index = newIndex;            // phase is 0 (extension) or 1 (shadow) here
+                    if (STATS) { if (phase == 0) raysE++; else raysS++; }
+                    o = newO; d = newD; distance = newDist;
+                    invdir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    hitRef = -1; hu = 0.0f; hv = 0.0f; redo = false;
+                    pa = 0; pb = S - 1; ti = -1;
+                    cur = (ray_box(ts.rootMin[0], ts.rootMin[1], ts.rootMin[2], ts.rootMax[0], ts.rootMax[1], ts.rootMax[2], o, invdir) > 0.0f) ? 0 : kDone;   // WNode 0 is the root's
+                }
+            }
+            if (nIdle == 64 && phase == 2) break; // nothing in flight and both queues are exhausted (wave-uniform)
+            next = (next + (uint32_t)nIdle < end) ? next + (uint32_t)nIdle : end;
+        }
+
+        // ---- REPS steps; a burst (wave-uniform, decided once per iteration) adds one triangle test per step to the lanes with leaves pending
+        const bool pendingNow = (pb != (uint32_t)(S - 1)) || (ti >= 0);
+        const bool roomNow = pb >= pa && pb - pa >= (uint32_t)(kWideRoom - 1);
+        if (cur >= 0 && !roomNow && !pendingNow) {
+            // the inner stack alone fills the LDS share of this lane: this ray's wide walk is given up, the exact walk (which spills) takes it
+            redo = true; cur = kDone; pa = bottom;
+        }
+        const int nPending = __popcll(__ballot(pendingNow));
+        const int nWalking = __popcll(__ballot(cur >= 0 && roomNow));
+        const bool burst = nPending >= (int)p.tuneTriThresh || (nWalking == 0 && nPending > 0); // wave-uniform
+        if (STATS) { // lane census: where do the 64 lanes of a wave spend the loop iterations?
+            census0 += __popcll(__ballot(cur == kDone && !pendingNow)); census1 += __popcll(__ballot(cur >= 0 && roomNow));
+            census2 += __popcll(__ballot(cur >= 0 && !roomNow)); census3 += __popcll(__ballot(cur == kDone && pendingNow));
+        }
+#pragma unroll
+        for (int rep = 0; rep < REPS; rep++) {
+            // fetch phase
+            const bool doNode = cur >= 0 && pb >= pa && pb - pa >= (uint32_t)(kWideRoom - 1);
+            vec4f q0, q1, q2, q3, q4, q5; vec4i lk;           // defined for the doNode lanes only
+            if (doNode) load_wnode(rNodes, s_top, topCount, cur, q0, q1, q2, q3, q4, q5, lk);
+            if (burst && ti < 0 && pb != (uint32_t)(S - 1)) { pb++; ti = ~sl[pb * kDefBlock]; }
+            const bool doTri = burst && ti >= 0;
+            vec4f r0, r1; vec2f r2;                          // defined for the doTri lanes only
+            if (doTri) tri_fetch_buf(rTris, ti, r0, r1, r2);
+            // compute phase
+            if (doNode) {
+                if (STATS) { if (kind == 0) tcE.inner++; else tcS.inner++; if (prefix_rank(__ballot(1)) == 0) { if (phase == 0) wInE++; else wInS++; }
+                             if ((uint32_t)cur < topCount) { if (kind == 0) topE++; else topS++; }
+                             boxes += (uint32_t)ts.wnodes[cur].aux[1]; }
+                const bool h0 = slab_hit(q0.x, q1.x, q2.x, q3.x, q4.x, q5.x, o, invdir), h1 = slab_hit(q0.y, q1.y, q2.y, q3.y, q4.y, q5.y, o, invdir);
+                const bool h2 = slab_hit(q0.z, q1.z, q2.z, q3.z, q4.z, q5.z, o, invdir), h3 = slab_hit(q0.w, q1.w, q2.w, q3.w, q4.w, q5.w, o, invdir);
+                int nxt = kDone;
+#define GMUPT_WIDE_SLOT(H, L) \
+                if (H) { const int l = (L); \
+                    if (l >= 0) { if (nxt < 0) nxt = l; else { sl[pa * kDefBlock] = l; pa++; } } \
+                    else { sl[pb * kDefBlock] = l; pb--; if (STATS) { if (kind == 0) tcE.leaves++; else tcS.leaves++; } } }
+                GMUPT_WIDE_SLOT(h0, lk.x) GMUPT_WIDE_SLOT(h1, lk.y) GMUPT_WIDE_SLOT(h2, lk.z) GMUPT_WIDE_SLOT(h3, lk.w)
+#undef GMUPT_WIDE_SLOT
+                if (nxt < 0) {
+                    if (pa > bottom) { pa--; nxt = sl[pa * kDefBlock]; }
+                    else { pa = 0; bottom = 0; }   // the inner stack is empty: its dead entries (given to helpers) are free again
+                }
+                cur = nxt;
+            }
+            if (doTri) {
+                if (STATS) { if (kind == 0) tcE.tris++; else tcS.tris++; if (prefix_rank(__ballot(1)) == 0) { if (phase == 0) wTrE++; else wTrS++; } }
+                float t = 0.0f, u = 0.0f, v = 0.0f; bool last;
+                if (tri_compute_flat(make_float4(r0.x, r0.y, r0.z, r0.w), make_float4(r1.x, r1.y, r1.z, r1.w),
+                                     make_float4(r2.x, r2.y, 0.0f, 0.0f), o, d, t, u, v, last)) {
+                    if (kind == 0) {
+                        if (t >= 0.0f && t < distance) { distance = t; hitRef = ti; hu = u; hv = v; redo = false; } // extensionRayCast.hlsl:64-74 (a closer hit ends a tie; a full stack ends the walk, so no test follows it)
+                        else if (t == distance && hitRef >= 0) { if (tri_canon(rTris, ti) != tri_canon(rTris, hitRef)) redo = true; } // which one the reference keeps depends on its visit order
+                    } else {
+                        // shadowRayCast.hlsl:41-45,89: t in (1e-8, 1e8) and |d t| < lightDistance => occluded: the ray is decided
+                        if (t > kEpsilon && t < 1.0f / kEpsilon && length3(d * t) < distance) { hitRef = ti; last = true; pb = S - 1; cur = kDone; pa = bottom; redo = false; }
+                    }
+                }
+                ti = last ? -1 : ti + 1;
+            }
+        }
+    }
+#undef GMUPT_WIDE_MERGE_OWN
+#undef GMUPT_WIDE_FINISH
+    if (STATS) { flush_counts(p.stats, tcE, raysE, true); flush_wave_iters(p.stats, wInE, wTrE, true);
+                 flush_counts(p.stats, tcS, raysS, false); flush_wave_iters(p.stats, wInS, wTrS, false);
+                 flush_sum(&p.stats->extTopInner, topE); flush_sum(&p.stats->shTopInner, topS); flush_sum(&p.stats->castHelperSubtrees, helped);
+                 flush_sum(&p.stats->castNestedHelpers, nested); flush_sum(&p.stats->wideBoxTests, boxes);
+                 if (lane == 0u) {
+                     atomicAdd(&p.stats->castWaves, 1ull);
+                     atomicAdd(&p.stats->laneCensus[0], (unsigned long long)census0); atomicAdd(&p.stats->laneCensus[1], (unsigned long long)census1);
+                     atomicAdd(&p.stats->laneCensus[2], (unsigned long long)census2); atomicAdd(&p.stats->laneCensus[3], (unsigned long long)census3);
+                 } }
+}
+
+// ------------------------------------------------------------------------------------------------ host launchers
+uint32_t traversal_wide_top_capacity() { return (uint32_t)kWideTop; }
+uint32_t traversal_wide_stack_entries() { return (uint32_t)kWideStack; }
+uint32_t traversal_wide_overflow_entries() { return (uint32_t)kWideOvf; }
+
+// Both ray casts in one wide launch.  Returns 0 when this configuration is not taken (the caller runs another kernel).
+uint32_t launch_cast_wide(const RenderParams& p, bool stats, hipStream_t s)
+{
+    if (!p.trav.wnodes || p.extendPrune || p.shadowPrune) return 0u;
+    if ((uint64_t)p.trav.wideCount * 128ull >= (1ull << 31) || ((uint64_t)p.scene.numTris + 1ull) * 48ull >= (1ull << 31)) return 0u;
+    const uint32_t pb = p.travGridBlocks;
+    if (stats) hipLaunchKernelGGL((k_cast_w<true>), dim3(pb), dim3(kDefBlock), 0, s, p);
+    else hipLaunchKernelGGL((k_cast_w<false>), dim3(pb), dim3(kDefBlock), 0, s, p);
+    return GMUPT_STAT_FUSED_CAST | GMUPT_STAT_CAST_WIDE;
+}
+
+} // namespace gmupt

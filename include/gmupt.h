@@ -43,7 +43,11 @@ typedef enum {
     GMUPT_ERR_OUT_OF_MEMORY = -3,
     GMUPT_ERR_NOT_BOUND = -4,    /* renderer used before a scene / camera was bound */
     GMUPT_ERR_UNSUPPORTED = -5,
-    GMUPT_ERR_IO = -6
+    GMUPT_ERR_IO = -6,
+    GMUPT_ERR_CAST_FAULT = -7    /* a ray-cast launch flagged its own results as invalid (GMUPT_STAT_STACK_OVERFLOW or GMUPT_STAT_CAST_ABORTED): returned by every
+                                    call that hands out or waits for a frame -- gmupt_synchronize, gmupt_read_framebuffer, gmupt_copy_framebuffer_to_device,
+                                    gmupt_get_stats (the statistics are still filled in), gmupt_render_budget -- until gmupt_reset_stats; the C++ Renderer throws,
+                                    like the reference on a failed device call (Source/Renderer.cpp:286-297) */
 } gmupt_status;
 
 /* ---- POD layouts shared with the reference (sizes are static_assert'ed in the implementation) ---- */
@@ -158,6 +162,7 @@ int gmupt_synchronize(gmupt_renderer* r);
 #define GMUPT_STAT_CAST_FETCH 4u     /* that launch was k_cast_f (the default kernel; it needs node / triangle arrays below 2 GiB each) */
 #define GMUPT_STAT_CAST_ABORTED 16u  /* a wave of the fused ray cast left its loop at the iteration limit (2^20 loop iterations; a bench-scene wave runs
                                         ~150): a defect, results invalid -- the kernel ends whatever happens */
+#define GMUPT_STAT_CAST_WIDE 32u     /* that launch was k_cast_w: the walk over the 4-wide collapse of the tree (GMUPT_TRAVERSAL=wide) */
 #define GMUPT_STAT_STACK_SPILL 8u    /* the tree is deeper than the LDS part of the traversal stacks: the instantiation with the bounds-checked
                                         global spill ran (results are the same; GMUPT_STAT_STACK_OVERFLOW is the error flag) */
 typedef struct {
@@ -185,6 +190,10 @@ typedef struct {
     uint64_t ray_inner_hist[32];      /* extension rays by inner nodes visited, 16 per bucket */
     uint64_t ext_top_inner, sh_top_inner; /* inner-node visits served by the LDS-resident top of the tree (k_cast_f, collect_stats) */
     uint64_t cast_helper_subtrees;        /* deferred subtrees walked by a finished lane for a lane still walking, in the drain of k_cast_f (collect_stats) */
+    uint64_t cast_nested_helpers;         /* of those: subtrees a helper lane gave away in turn (collect_stats) */
+    uint64_t cast_redo_rays;              /* wide ray cast: rays walked again in the reference's binary order (their closest hit was an exact tie in t between
+                                             two triangles, or a traversal stack ran full) */
+    uint64_t wide_box_tests;              /* wide ray cast, collect_stats: occupied box slots tested */
 } gmupt_stats;
 int gmupt_get_stats(gmupt_renderer* r, gmupt_stats* out); /* synchronises */
 int gmupt_reset_stats(gmupt_renderer* r);

@@ -436,23 +436,43 @@ def test_error_convention_on_device(pkg, device, cornell_scene):
 
 def test_ray_cast_watchdog_ends_the_launch_and_flags_it(pkg, device, spheres_small_scene, monkeypatch):
     # the persistent ray-cast kernel must end whatever happens: with the iteration limit set absurdly low every wave gives up at once,
-    # the launch returns and the statistics say that its results are invalid; with the default limit the flag stays clear
+    # the launch returns, the statistics say that its results are invalid AND every call that waits for or hands out a frame fails
+    # (GMUPT_ERR_CAST_FAULT) until gmupt_reset_stats; with the default limit the flag stays clear and the same calls succeed
     capi = pkg.capi
     sb = capi.SceneBuffers(device, spheres_small_scene)
 
-    def run(cap):
+    def make(cap, budget=0):
         if cap: monkeypatch.setenv("GMUPT_CAST_LOOP_CAP", str(cap))
         else: monkeypatch.delenv("GMUPT_CAST_LOOP_CAP", raising=False)
-        r = capi.Renderer(device, 96, 54, pool_paths=1 << 16)
+        r = capi.Renderer(device, 96, 54, pool_paths=1 << 16, path_budget=budget)
         r.bind_scene(sb)
         cam = capi.Camera(96, 54); cam.set_pose(*spheres_small_scene["camera"]); cam.buffer.lightCount = spheres_small_scene["light_count"]
-        for _ in range(6):
-            cam.update(0.0); r.set_camera(cam.buffer); r.iterate()
-        r.synchronize()
-        flags = r.stats().flags
-        r.close()
-        return flags
+        return r, cam
 
-    assert run(2) & capi.STAT_CAST_ABORTED
-    assert not (run(0) & (capi.STAT_CAST_ABORTED | capi.STAT_STACK_OVERFLOW))
+    r, cam = make(2)
+    for _ in range(6):
+        cam.update(0.0); r.set_camera(cam.buffer); r.iterate()
+    for call in (r.synchronize, r.framebuffer, r.stats):
+        with pytest.raises(capi.GmuptError, match="invalid") as e:
+            call()
+        assert e.value.code == capi.ERR_CAST_FAULT
+    assert r.stats(check=False).flags & capi.STAT_CAST_ABORTED
+    import torch
+    dst = torch.empty((54, 96, 4), dtype=torch.float32, device="cuda")
+    with pytest.raises(capi.GmuptError, match="invalid"):
+        r.copy_framebuffer_to_device(dst.data_ptr(), dst.numel() * 4)
+    r.reset_stats()                      # the flag is sticky until the statistics are reset
+    r.synchronize()
+    r.close()
+    r, cam = make(2, budget=96 * 54 * 2)
+    with pytest.raises(capi.GmuptError, match="invalid") as e:
+        r.render_budget(cam, 1000)
+    assert e.value.code == capi.ERR_CAST_FAULT
+    r.close()
+    r, cam = make(0)
+    for _ in range(6):
+        cam.update(0.0); r.set_camera(cam.buffer); r.iterate()
+    r.synchronize(); r.framebuffer()
+    assert not (r.stats().flags & (capi.STAT_CAST_ABORTED | capi.STAT_STACK_OVERFLOW))
+    r.close()
     sb.close()

@@ -1,0 +1,197 @@
+"""GPU parity tests of the wide ray cast (GMUPT_TRAVERSAL=wide: k_cast_w over the 4-wide collapse of the SBVH).
+
+The wide walk visits the reference's leaves in another order and skips some of its box tests (pt_traverse_wide.hip explains why the
+leaves are the same, also for rays with zero direction components on flat boxes); what the order could change -- exact ties in t
+between two triangles -- is noticed, and those rays are walked again in the reference's binary order inside the same launch.  Bar as everywhere:
+path state, queues, counters and framebuffer bit for bit against the CPU oracle.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import parity_util as PU
+from test_parity_gpu import _assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def wide(monkeypatch):
+    monkeypatch.setenv("GMUPT_TRAVERSAL", "wide")
+
+
+@pytest.mark.parametrize("scene_name,W,H,P,L,iters", [
+    ("cornell", 64, 36, 4096, 0, 30),
+    ("cornell", 32, 18, 8192, 6144, 12),
+    ("soup", 48, 27, 2048, 0, 40),
+    ("spheres", 48, 27, 2048, 0, 120),
+    ("textured", 48, 27, 2048, 0, 40),
+])
+def test_wide_iteration_parity(pkg, device, wide, cornell_scene, soup_scene, spheres_small_scene, scene_name, W, H, P, L, iters):
+    scene = {"cornell": cornell_scene, "soup": soup_scene, "spheres": spheres_small_scene}[scene_name] if scene_name != "textured" \
+        else pkg.scenes.build_scene(pkg.scenes.textured_mesh())
+    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, scene, W, H, P, live=L)
+    live = L or P
+    for it in range(iters):
+        PU.step_both(orc, hip, ocam, hcam)
+        if it < 6 or it % 10 == 9 or it == iters - 1:
+            _assert_same(orc, hip, P, live, it)
+    sh = hip.stats()
+    assert sh.flags & pkg.capi.STAT_CAST_WIDE, "the wide kernel did not run"
+    assert not (sh.flags & (pkg.capi.STAT_STACK_OVERFLOW | pkg.capi.STAT_CAST_ABORTED))
+    hip.close(); sb.close(); orc.close()
+
+
+def test_wide_statistics(pkg, device, wide, soup_scene):
+    # leaves reached and triangles tested by the extension rays are the reference's (the visited set does not depend on the order or on
+    # which ancestors are tested); the wide nodes visited are about half the binary inner nodes
+    W, H, P = 32, 18, 1024
+    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, soup_scene, W, H, P, collect_stats=True)
+    for it in range(10):
+        PU.step_both(orc, hip, ocam, hcam)
+    _assert_same(orc, hip, P, P, 9)
+    so, sh = orc.stats(), hip.stats()
+    assert sh.flags & pkg.capi.STAT_CAST_WIDE
+    redo = sh.cast_redo_rays
+    assert so.extRays == sh.ext_rays and so.shRays == sh.sh_rays
+    if redo == 0:
+        assert (so.extLeaves, so.extTris) == (sh.ext_leaves, sh.ext_tris)
+    assert 0 < sh.ext_inner < 0.7 * so.extInner
+    assert sh.wide_box_tests > 0 and sh.cast_helper_subtrees > 0
+    hip.close(); sb.close(); orc.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_wide_on_grid_meshes_with_exact_ties(pkg, device, wide, seed):
+    # the adversarial meshes of test_ray_casts_on_grid_meshes_with_exact_ties: coplanar duplicates, shared edges, rays along grid
+    # directions from grid points: zero direction components with origins exactly on box planes (flat boxes!), and exact ties
+    rng = np.random.default_rng(seed)
+    n_tris = int(rng.integers(20, 400))
+    grid = int(rng.choice([3, 5, 9]))
+    nv = max(4, n_tris // 2)
+    verts = (rng.integers(0, grid, (nv, 3)) * (8.0 / (grid - 1)) - 4.0).astype(np.float32)
+    idx = rng.integers(0, nv, (n_tris, 3)).astype(np.int32)
+    idx[: n_tris // 5] = idx[n_tris // 5: 2 * (n_tris // 5)][: n_tris // 5]
+    mesh = pkg.scenes.cornell_mesh()
+    normals = np.tile(np.array([0.0, 1.0, 0.0], np.float32), (nv, 1))
+    mesh.update({"verts": verts, "normals": normals, "indices": idx, "vertex_material": (rng.integers(0, 3, nv)).astype(np.uint32), "name": "grid%d" % seed})
+    mesh.pop("uv", None)
+    scene = pkg.scenes.build_scene(mesh)
+    P = 4096
+    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, scene, 32, 18, P, collect_stats=True)
+    pts = (rng.integers(0, grid, (P, 3)) * (8.0 / (grid - 1)) - 4.0).astype(np.float32)
+    dirs = rng.integers(-2, 3, (P, 3)).astype(np.float32); dirs[(dirs == 0).all(axis=1)] = (1.0, 0.0, 0.0)
+    # a third of the rays with all components non-zero (they stay in the wide walk and meet ties), normalised or not
+    nz = rng.choice(np.array([-2.0, -1.0, 1.0, 2.0], np.float32), (P, 3))
+    third = np.arange(P) % 3 == 0
+    dirs[third] = nz[third]
+    dirs[: P // 2] /= np.linalg.norm(dirs[: P // 2], axis=1, keepdims=True)
+    o = (pts - dirs * rng.integers(1, 4, (P, 1)).astype(np.float32)).astype(np.float32)
+    st = orc.path_state()
+    O.state_field(st, P, "rayOrigin").view(np.float32)[:] = o; O.state_field(st, P, "rayDirection").view(np.float32)[:] = dirs
+    O.state_field(st, P, "shadowrayOrigin").view(np.float32)[:] = o; O.state_field(st, P, "shadowrayDirection").view(np.float32)[:] = dirs
+    O.state_field(st, P, "lightDistance").view(np.float32)[:, 0] = rng.uniform(0.5, 12.0, P).astype(np.float32)
+    orc.queues()[3][:] = np.arange(P, dtype=np.uint32); orc.queues()[4][:] = np.arange(P, dtype=np.uint32)[::-1]
+    qc = orc.counters(); qc[:] = 0; qc[6] = P; qc[7] = P
+    ocam.update(); hcam.update(0.0); orc.set_camera(ocam.buffer); hip.set_camera(hcam.buffer)
+    frozen = (orc.path_state().copy(), orc.queues().copy(), orc.counters().copy())
+    orc.stage("extension"); orc.stage("shadow")
+    fields = ["surfacePoint", "baryCoord", "triangle", "isEmitter", "hitDistance", "inShadow"]
+    hip.write_path_state(frozen[0]); hip.write_queues(frozen[1]); hip.write_counters(frozen[2])
+    hip.run_stage(pkg.capi.STAGE_RAYCASTS)
+    bad = PU.compare_state(orc, hip, P, P, fields=fields)
+    assert not bad, bad[:3]
+    sh = hip.stats()
+    assert sh.flags & pkg.capi.STAT_CAST_WIDE
+    n_inf = int((dirs == 0).any(axis=1).sum())
+    assert sh.cast_redo_rays > 0, "exact ties must go to the exact walk"
+    print("grid %d: %d of %d rays with a zero component, %d rays walked again (of %d)" % (seed, n_inf, P, sh.cast_redo_rays, 2 * P))
+    hip.close(); sb.close(); orc.close()
+
+
+def test_wide_ties_without_zero_components(pkg, device, wide):
+    # two coplanar, overlapping triangles of different materials and a fan of triangles around a shared vertex: rays with non-zero,
+    # exactly representable direction components hit them at bitwise equal t -- the wide walk must notice and defer to the exact walk
+    mesh = pkg.scenes.cornell_mesh()
+    verts = np.array([[-2, 0, -2], [2, 0, -2], [2, 0, 2], [-2, 0, 2],            # square y = 0, two triangles
+                      [-2, 0, -2], [2, 0, -2], [2, 0, 2], [-2, 0, 2],            # the same square again (other material)
+                      [0, 1, 0], [1, 1, 0], [0, 1, 1], [-1, 1, 0], [0, 1, -1]],  # a fan at y = 1 around (0, 1, 0)
+                     np.float32)
+    idx = np.array([[0, 1, 2], [0, 2, 3], [4, 5, 6], [4, 6, 7], [8, 9, 10], [8, 10, 11], [8, 11, 12], [8, 12, 9]], np.int32)
+    vm = np.array([0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 2], np.uint32)
+    mesh.update({"verts": verts, "normals": np.tile(np.array([0.0, 1.0, 0.0], np.float32), (len(verts), 1)), "indices": idx, "vertex_material": vm, "name": "ties"})
+    mesh.pop("uv", None)
+    scene = pkg.scenes.build_scene(mesh)
+    P = 2048
+    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, scene, 32, 18, P, collect_stats=True)
+    rng = np.random.default_rng(11)
+    target = np.zeros((P, 3), np.float32)
+    target[:, 0] = rng.integers(-7, 8, P) * 0.25; target[:, 2] = rng.integers(-7, 8, P) * 0.25
+    target[P // 2:] = (0.0, 1.0, 0.0)                                            # the fan's shared vertex
+    target[P // 2:, 0] += rng.integers(-2, 3, P - P // 2) * 0.25
+    dirs = rng.choice(np.array([-1.0, -0.5, 0.5, 1.0], np.float32), (P, 3)); dirs[:, 1] = -np.abs(dirs[:, 1])
+    o = (target - dirs * rng.integers(1, 5, (P, 1)).astype(np.float32)).astype(np.float32)
+    st = orc.path_state()
+    O.state_field(st, P, "rayOrigin").view(np.float32)[:] = o; O.state_field(st, P, "rayDirection").view(np.float32)[:] = dirs
+    O.state_field(st, P, "shadowrayOrigin").view(np.float32)[:] = o; O.state_field(st, P, "shadowrayDirection").view(np.float32)[:] = dirs
+    O.state_field(st, P, "lightDistance").view(np.float32)[:, 0] = rng.uniform(0.5, 12.0, P).astype(np.float32)
+    orc.queues()[3][:] = np.arange(P, dtype=np.uint32); orc.queues()[4][:] = np.arange(P, dtype=np.uint32)
+    qc = orc.counters(); qc[:] = 0; qc[6] = P; qc[7] = P
+    ocam.update(); hcam.update(0.0); orc.set_camera(ocam.buffer); hip.set_camera(hcam.buffer)
+    frozen = (orc.path_state().copy(), orc.queues().copy(), orc.counters().copy())
+    orc.stage("extension"); orc.stage("shadow")
+    hip.write_path_state(frozen[0]); hip.write_queues(frozen[1]); hip.write_counters(frozen[2])
+    hip.run_stage(pkg.capi.STAGE_RAYCASTS)
+    bad = PU.compare_state(orc, hip, P, P, fields=["surfacePoint", "baryCoord", "triangle", "isEmitter", "hitDistance", "inShadow"])
+    assert not bad, bad[:3]
+    sh = hip.stats()
+    assert sh.cast_redo_rays > P // 8, "the coplanar squares tie on every ray that hits them: %d redo rays" % sh.cast_redo_rays
+    hip.close(); sb.close(); orc.close()
+
+
+def test_wide_deep_tree(pkg, device, wide):
+    scene = pkg.scenes.build_scene(pkg.scenes.deep_chain_mesh())
+    W, H, P = 48, 32, 2048
+    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, scene, W, H, P)
+    for it in range(12):
+        PU.step_both(orc, hip, ocam, hcam)
+        _assert_same(orc, hip, P, P, it)
+    sh = hip.stats()
+    assert sh.flags & pkg.capi.STAT_CAST_WIDE and not (sh.flags & pkg.capi.STAT_STACK_OVERFLOW)
+    hip.close(); sb.close(); orc.close()
+
+
+@pytest.mark.parametrize("knobs", [
+    {"GMUPT_RAYS_PER_WAVE": "64", "GMUPT_REFILL": "1", "GMUPT_TRI_THRESH": "1", "GMUPT_WAVES_PER_CU": "4"},
+    {"GMUPT_RAYS_PER_WAVE": "128", "GMUPT_REFILL": "64", "GMUPT_TRI_THRESH": "64", "GMUPT_WAVES_PER_CU": "16"},
+], ids=["eager", "lazy"])
+def test_wide_results_do_not_depend_on_scheduling_knobs(pkg, device, wide, spheres_small_scene, monkeypatch, knobs):
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    W, H, P = 48, 27, 4096
+    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, spheres_small_scene, W, H, P)
+    for it in range(16):
+        PU.step_both(orc, hip, ocam, hcam)
+    _assert_same(orc, hip, P, P, 16)
+    hip.close(); sb.close(); orc.close()
+
+
+@pytest.mark.parametrize("scene_name", ["soup", "spheres"])
+def test_wide_with_tiny_stacks_parks_rays_for_the_exact_walk(pkg, monkeypatch, soup_scene, spheres_small_scene, scene_name):
+    # the wides8 test build gives a lane 8 LDS words for both stacks: the inner stack runs full all the time, the wide walk of such a ray is
+    # given up (owner or helper lane, extension or shadow ray) and the exact walk -- LDS share, then the bounds-checked global overflow --
+    # takes it: results bit for bit, many rays walked again, no error flag
+    monkeypatch.setenv("GMUPT_TRAVERSAL", "wide")
+    scene = {"soup": soup_scene, "spheres": spheres_small_scene}[scene_name]
+    W, H, P = 48, 27, 4096
+    with pkg.capi.use_build("wides8"):
+        dev = pkg.capi.Device(0)
+        orc, hip, ocam, hcam, sb = PU.make_pair(pkg, dev, scene, W, H, P, collect_stats=True)
+        for it in range(20):
+            PU.step_both(orc, hip, ocam, hcam)
+            if it in (0, 1, 5, 19):
+                _assert_same(orc, hip, P, P, it)
+        sh = hip.stats()
+        assert sh.flags & pkg.capi.STAT_CAST_WIDE and not (sh.flags & (pkg.capi.STAT_STACK_OVERFLOW | pkg.capi.STAT_CAST_ABORTED))
+        assert sh.cast_redo_rays > 500, "with 8-word stacks many rays must have been parked: %d of %d" % (sh.cast_redo_rays, sh.ext_rays + sh.sh_rays)
+        hip.close(); sb.close(); orc.close(); dev.close()
