@@ -62,7 +62,7 @@ class Stats(C.Structure):
                 ("cast_drain_ticks", C.c_uint64), ("cast_drain_iters", C.c_uint64), ("cast_drain_busy_lanes", C.c_uint64),
                 ("cast_wave_end_hist", C.c_uint64 * 32), ("ray_inner_hist", C.c_uint64 * 32),
                 ("ext_top_inner", C.c_uint64), ("sh_top_inner", C.c_uint64), ("cast_helper_subtrees", C.c_uint64),
-                ("cast_nested_helpers", C.c_uint64), ("cast_redo_rays", C.c_uint64), ("wide_box_tests", C.c_uint64)]
+                ("cast_nested_helpers", C.c_uint64), ("cast_redo_rays", C.c_uint64), ("wide_nodes", C.c_uint64), ("wide_top_nodes", C.c_uint64), ("wide_stack_bound", C.c_uint64), ("wide_box_tests", C.c_uint64)]
 
     def as_dict(self):
         return {n: (list(getattr(self, n)) if hasattr(getattr(self, n), "__len__") else getattr(self, n)) for n, _ in self._fields_}
@@ -142,6 +142,7 @@ SYMBOLS = {
 
 _lib = None
 _libs = {}
+_devices_created = 0   # gmupt_device_create calls of this process (a process that uses the GPU must not spawn a compiler)
 
 
 def _load(path):
@@ -177,6 +178,10 @@ class use_build:
         global _lib
         path = _build.lib_path(self.name)
         if not os.path.exists(path) or (os.path.exists("/opt/rocm/bin/hipcc") and _build.needs_build(self.name)):
+            if _devices_created:
+                # a process that has initialised the GPU must not start hipcc (fork + exec): the GPU box refuses it.  __graft_entry__.build()
+                # prebuilds every test build; a stale one is an error here, not something to repair on the fly
+                raise GmuptError("test build %r is missing or older than its sources and this process already uses the GPU: run __graft_entry__.build() first" % self.name)
             path = _build.build(name=self.name)
         self.saved = lib()
         _lib = _load(path)
@@ -199,8 +204,10 @@ def _ptr(a):
 
 class Device:
     def __init__(self, index=0):
+        global _devices_created
         self.h = _P()
         _check(lib().gmupt_device_create(index, C.byref(self.h)))
+        _devices_created += 1
 
     def close(self):
         if self.h:

@@ -214,7 +214,7 @@ struct gmupt_renderer {
     std::vector<void*> allocs;
     // packed traversal copy of the bound scene
     void* travNodes = nullptr; void* travTris = nullptr; void* travRecs = nullptr; void* travWide = nullptr;
-    int travMode = 60; // GMUPT_TRAVERSAL: "cast0" (default) both ray casts in one launch | "def0" separate launches; the other rungs of the ladder exist in -DGMUPT_VARIANTS builds only
+    int travMode = 70; // GMUPT_TRAVERSAL: "wide" (default) both ray casts in one launch over the 4-wide collapse | "cast0" the same over the binary tree | "def0" separate launches; the other rungs of the ladder exist in -DGMUPT_VARIANTS builds only
     uint32_t castFlags = 0; // GMUPT_STAT_* bits of the ray-cast kernels launched since the last reset
 };
 
@@ -259,7 +259,7 @@ extern "C" void gmupt_renderer_destroy(gmupt_renderer* r)
 // GMUPT_TRAVERSAL selects a rung of the traversal ladder; all rungs give identical results, the default is the fastest
 static int parse_traversal_mode(const char* tv)
 {
-    constexpr int kDefault = 60;                                            // cast0: both ray casts in one mixed-lane persistent launch, fetches fused
+    constexpr int kDefault = 70;                                            // wide: both ray casts in one launch over the 4-wide collapse of the tree (cast0, the binary fused kernel, takes what it does not)
     if (!tv || !*tv) return kDefault;
     if (std::strcmp(tv, "whilewhile") == 0) return 0;
     if (std::strcmp(tv, "ref") == 0) return 1;
@@ -285,7 +285,7 @@ extern "C" int gmupt_renderer_create(gmupt_device* dev, const gmupt_renderer_des
     r->travMode = parse_traversal_mode(std::getenv("GMUPT_TRAVERSAL"));
     if (!traversal_mode_available(r->travMode)) {
         delete r;
-        return fail(GMUPT_ERR_UNSUPPORTED, "gmupt_renderer_create: GMUPT_TRAVERSAL=%s is not part of this build (cast0 and def0 are; the other rungs need -DGMUPT_VARIANTS)", std::getenv("GMUPT_TRAVERSAL"));
+        return fail(GMUPT_ERR_UNSUPPORTED, "gmupt_renderer_create: GMUPT_TRAVERSAL=%s is not part of this build (wide, cast0 and def0 are; the other rungs need -DGMUPT_VARIANTS)", std::getenv("GMUPT_TRAVERSAL"));
     }
     if (r->desc.pool_paths == 0) r->desc.pool_paths = GMUPT_PATHCOUNT;
     if (r->desc.live_paths == 0 || r->desc.live_paths > r->desc.pool_paths) r->desc.live_paths = r->desc.pool_paths;
@@ -844,7 +844,7 @@ extern "C" int gmupt_get_stats(gmupt_renderer* r, gmupt_stats* out)
     out->cast_waves = ds.castWaves; out->cast_wave_ticks = ds.castWaveClocks; out->cast_wave_ticks_max = ds.castWaveClocksMax;
     out->cast_drain_ticks = ds.castDrainClocks; out->cast_drain_iters = ds.castDrainIters; out->cast_drain_busy_lanes = ds.castDrainBusyLanes;
     out->ext_top_inner = ds.extTopInner; out->sh_top_inner = ds.shTopInner; out->cast_helper_subtrees = ds.castHelperSubtrees;
-    out->cast_nested_helpers = ds.castNestedHelpers; out->cast_redo_rays = ds.castRedoRays; out->wide_box_tests = ds.wideBoxTests;
+    out->cast_nested_helpers = ds.castNestedHelpers; out->cast_redo_rays = ds.castRedoRays; out->wide_nodes = r->p.trav.wideCount; out->wide_top_nodes = r->p.trav.wideTopCount; out->wide_stack_bound = r->p.trav.wideStackBound; out->wide_box_tests = ds.wideBoxTests;
     out->ext_wave_inner = ds.extWaveInner; out->ext_wave_tris = ds.extWaveTris; out->sh_wave_inner = ds.shWaveInner; out->sh_wave_tris = ds.shWaveTris;
     if (ds.stackOverflow & 3u) return fail(GMUPT_ERR_CAST_FAULT, "gmupt_get_stats: a ray-cast launch flagged its results as invalid (flags %#x; the statistics are filled in)", out->flags);
     return GMUPT_OK;

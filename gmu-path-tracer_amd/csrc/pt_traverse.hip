@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kDefBlock) GMUPT_CAST_OCCUPANCY void k_cast_f(Rende
 #endif
     const unsigned long long tStart = (STATS || GMUPT_DRAIN_TIMING) ? wall_clock64() : 0ull;
     unsigned long long tDrain = 0ull; uint32_t drainIters = 0, drainBusy = 0;
-    uint32_t rayInner = 0, census0 = 0, census1 = 0, census2 = 0, census3 = 0, topE = 0, topS = 0, helped = 0;
+    uint32_t rayInner = 0, census0 = 0, census1 = 0, census2 = 0, census3 = 0, topE = 0, topS = 0, helped = 0, nested = 0;
 
     bool haveRay = false;
     int kind = 0;                 // 0: extension ray, 1: shadow ray
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(kDefBlock) GMUPT_CAST_OCCUPANCY void k_cast_f(Rende
                     int* slot = s_stack + bottom * kDefBlock + threadIdx.x;
                     node = *slot; *slot = kDone;           // the slot becomes the sentinel of what is left of the owner's stack
                     bottom++; outstanding++; donations++;
-                    if (STATS) helped++;
+                    if (STATS) { helped++; if (owner >= 0) nested++; }   // nested: a helper gives a part of ITS subtree away
                 }
                 // lane k learns which lane the k-th donor is; a taker with rank k reads that number from lane k, then the ray from the donor
                 const int donorOfRank = __builtin_amdgcn_ds_permute((int)((gives ? dRank : 63u) << 2), gives ? (int)lane : 0);
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(kDefBlock) GMUPT_CAST_OCCUPANCY void k_cast_f(Rende
     }
     if (STATS) { flush_counts(p.stats, tcE, raysE, true); flush_wave_iters(p.stats, wInE, wTrE, true);
                  flush_counts(p.stats, tcS, raysS, false); flush_wave_iters(p.stats, wInS, wTrS, false);
-                 flush_sum(&p.stats->extTopInner, topE); flush_sum(&p.stats->shTopInner, topS); flush_sum(&p.stats->castHelperSubtrees, helped);
+                 flush_sum(&p.stats->extTopInner, topE); flush_sum(&p.stats->shTopInner, topS); flush_sum(&p.stats->castHelperSubtrees, helped); flush_sum(&p.stats->castNestedHelpers, nested);
                  if ((threadIdx.x & 63) == 0) {
                      const unsigned long long tEnd = wall_clock64();
                      const unsigned long long life = tEnd - tStart;

@@ -33,13 +33,13 @@
 namespace gmupt {
 
 #ifndef GMUPT_WIDE_STACK
-#define GMUPT_WIDE_STACK 28
+#define GMUPT_WIDE_STACK 24
 #endif
 #ifndef GMUPT_WIDE_TOP
-#define GMUPT_WIDE_TOP 384
+#define GMUPT_WIDE_TOP 512
 #endif
 #ifndef GMUPT_WIDE_REPS
-#define GMUPT_WIDE_REPS 4
+#define GMUPT_WIDE_REPS 6
 #endif
 #ifndef GMUPT_WIDE_PARK
 #define GMUPT_WIDE_PARK 16
@@ -92,6 +92,53 @@ __device__ __forceinline__ uint32_t tri_canon(__amdgpu_buffer_rsrc_t tris, int i
     return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(tris, i * 48 + 40, 0, 0);
 }
 
+// The four slab tests of a step on packed binary32 arithmetic: (plane - o) * (1 / d) for two slots per v_pk_add_f32 / v_pk_mul_f32 -- the
+// same IEEE operations on the same operands as the scalar form, two at a time -- and the min / max tree as the machine instructions
+// themselves.  (Written with __builtin_fminf the compiler puts a canonicalising v_max x, x in front of every product of a packed
+// multiply -- 24 extra instructions per step; v_min / v_max / v_min3 / v_max3 return the non-NaN operand like the HLSL min / max, and
+// no operand here can be a signalling NaN: products and the quiet NaNs of empty slots.)
+#ifndef GMUPT_WIDE_PK
+#define GMUPT_WIDE_PK 1
+#endif
+__device__ __forceinline__ float v_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float v_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float v_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float v_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ bool slab_hit_pk(float nx, float ny, float nz, float fx, float fy, float fz)
+{
+    const float t1 = v_min3(v_max(fx, nx), v_max(fy, ny), v_max(fz, nz));
+    const float t0 = v_max3(v_min(fx, nx), v_min(fy, ny), v_min(fz, nz));
+    return (t1 >= t0) & (t1 > 0.0f);
+}
+// The ray's origin and 1 / d live in three register PAIRS -- (o.x, o.y), (1/d.x, 1/d.y), (o.z, 1/d.z) -- so that every packed instruction
+// takes its broadcast operand from one half of an aligned pair (op_sel) without a copy.
+struct RayPk { vec2f oxy, ixy, ozi; };
+__device__ __forceinline__ f3 ray_o(const RayPk& r) { return mk3(r.oxy.x, r.oxy.y, r.ozi.x); }
+__device__ __forceinline__ f3 ray_inv(const RayPk& r) { return mk3(r.ixy.x, r.ixy.y, r.ozi.y); }
+__device__ __forceinline__ void ray_set(RayPk& r, f3 o, f3 d) { r.oxy.x = o.x; r.oxy.y = o.y; r.ozi.x = o.z; r.ixy.x = 1.0f / d.x; r.ixy.y = 1.0f / d.y; r.ozi.y = 1.0f / d.z; }
+
+__device__ __forceinline__ void slab_hits4(const vec4f q0, const vec4f q1, const vec4f q2, const vec4f q3, const vec4f q4, const vec4f q5, const RayPk& ray,
+                                           bool& h0, bool& h1, bool& h2, bool& h3)
+{
+#if GMUPT_WIDE_PK
+    const vec2f ox = __builtin_shufflevector(ray.oxy, ray.oxy, 0, 0), oy = __builtin_shufflevector(ray.oxy, ray.oxy, 1, 1), oz = __builtin_shufflevector(ray.ozi, ray.ozi, 0, 0);
+    const vec2f ix = __builtin_shufflevector(ray.ixy, ray.ixy, 0, 0), iy = __builtin_shufflevector(ray.ixy, ray.ixy, 1, 1), iz = __builtin_shufflevector(ray.ozi, ray.ozi, 1, 1);
+#define GMUPT_LO(Q) __builtin_shufflevector(Q, Q, 0, 1)
+#define GMUPT_HI(Q) __builtin_shufflevector(Q, Q, 2, 3)
+    const vec2f nxa = (GMUPT_LO(q0) - ox) * ix, nxb = (GMUPT_HI(q0) - ox) * ix, nya = (GMUPT_LO(q1) - oy) * iy, nyb = (GMUPT_HI(q1) - oy) * iy;
+    const vec2f nza = (GMUPT_LO(q2) - oz) * iz, nzb = (GMUPT_HI(q2) - oz) * iz, fxa = (GMUPT_LO(q3) - ox) * ix, fxb = (GMUPT_HI(q3) - ox) * ix;
+    const vec2f fya = (GMUPT_LO(q4) - oy) * iy, fyb = (GMUPT_HI(q4) - oy) * iy, fza = (GMUPT_LO(q5) - oz) * iz, fzb = (GMUPT_HI(q5) - oz) * iz;
+#undef GMUPT_LO
+#undef GMUPT_HI
+    h0 = slab_hit_pk(nxa.x, nya.x, nza.x, fxa.x, fya.x, fza.x); h1 = slab_hit_pk(nxa.y, nya.y, nza.y, fxa.y, fya.y, fza.y);
+    h2 = slab_hit_pk(nxb.x, nyb.x, nzb.x, fxb.x, fyb.x, fzb.x); h3 = slab_hit_pk(nxb.y, nyb.y, nzb.y, fxb.y, fyb.y, fzb.y);
+#else
+    const f3 o = ray_o(ray), invdir = ray_inv(ray);
+    h0 = slab_hit(q0.x, q1.x, q2.x, q3.x, q4.x, q5.x, o, invdir); h1 = slab_hit(q0.y, q1.y, q2.y, q3.y, q4.y, q5.y, o, invdir);
+    h2 = slab_hit(q0.z, q1.z, q2.z, q3.z, q4.z, q5.z, o, invdir); h3 = slab_hit(q0.w, q1.w, q2.w, q3.w, q4.w, q5.w, o, invdir);
+#endif
+}
+
 template <bool STATS>
 __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
 {
@@ -122,7 +169,8 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
     bool haveRay = false;
     int kind = 0;                 // 0: extension ray, 1: shadow ray; 2 / 3: the same, PARKED for the exact walk
     uint32_t index = 0;
-    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), invdir = mk3(0, 0, 0);
+    RayPk ray; ray_set(ray, mk3(0, 0, 0), mk3(1, 1, 1));   // origin and 1 / d of the lane's ray
+    f3 d = mk3(0, 0, 1);
     float distance = kFltMax;     // extension: closest hit so far; shadow: distance of the light
     float hu = 0.0f, hv = 0.0f;
     int hitRef = -1;              // extension: triangle record of the closest hit; shadow: >= 0 when occluded
@@ -147,7 +195,7 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
          tT = kFltMax; refT = -1; redoT = false; } while (0)
     // the end of a decided ray in its lane
 #define GMUPT_WIDE_FINISH() \
-    do { if (kind == 0) finish_extension_ray(p, index, o, d, distance, hu, hv, hitRef);            /* extensionRayCast.hlsl:218-232 */ \
+    do { if (kind == 0) finish_extension_ray(p, index, ray_o(ray), d, distance, hu, hv, hitRef);   /* extensionRayCast.hlsl:218-232 */ \
          else stu(p, F_IN_SHADOW, index, hitRef >= 0 ? 1u : 0u);                                    /* shadowRayCast.hlsl:167 */ \
          haveRay = false; redo = false; } while (0)
 
@@ -210,11 +258,11 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
                 const int src = __shfl(donorOfRank, takes ? (int)fRank : 0);
                 const int srcLane = takes ? src : (int)lane;
                 const int node2 = __shfl(node, srcLane), k2 = __shfl(kind, srcLane), i2 = __shfl((int)index, srcLane);
-                const float ox = __shfl(o.x, srcLane), oy = __shfl(o.y, srcLane), oz = __shfl(o.z, srcLane), dx = __shfl(d.x, srcLane), dy = __shfl(d.y, srcLane), dz = __shfl(d.z, srcLane);
+                const float ox = __shfl(ray.oxy.x, srcLane), oy = __shfl(ray.oxy.y, srcLane), oz = __shfl(ray.ozi.x, srcLane), dx = __shfl(d.x, srcLane), dy = __shfl(d.y, srcLane), dz = __shfl(d.z, srcLane);
                 const float lim = __shfl(distance, srcLane);
                 if (takes) {
                     haveRay = true; owner = src; kind = k2; index = (uint32_t)i2; donations = 0;
-                    o = mk3(ox, oy, oz); d = mk3(dx, dy, dz); invdir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    d = mk3(dx, dy, dz); ray_set(ray, mk3(ox, oy, oz), d);
                     distance = k2 == 1 ? lim : kFltMax;     // shadow: the distance of the light; extension: no hit yet
                     hitRef = -1; hu = 0.0f; hv = 0.0f; redo = false;
                     pa = 0; bottom = 0; pb = S - 1; outstanding = 0; ti = -1;
@@ -238,10 +286,10 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
                 if (lane == 0u) atomicAdd(&p.stats->castRedoRays, (unsigned long long)nParked);
                 if (parked) {
                     const bool shadowRay = kind == 3;
-                    o = shadowRay ? ld3(p, F_SH_OX, index) : ld3(p, F_RAY_OX, index);
                     d = shadowRay ? ld3(p, F_SH_DX, index) : ld3(p, F_RAY_DX, index);
+                    ray_set(ray, shadowRay ? ld3(p, F_SH_OX, index) : ld3(p, F_RAY_OX, index), d);
                     distance = shadowRay ? ldf(p, F_LIGHT_DIST, index) : kFltMax;
-                    invdir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    const f3 o = ray_o(ray), invdir = ray_inv(ray);
                     hitRef = -1; hu = 0.0f; hv = 0.0f;
                     int* ovf = p.ovfStack + gtid;
                     uint32_t sp = 0;
@@ -323,11 +371,11 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
                     bottom = 0; donations = 0;
                     haveRay = true; kind = phase; index = newIndex;            // phase is 0 (extension) or 1 (shadow) here
                     if (STATS) { if (phase == 0) raysE++; else raysS++; }
-                    o = newO; d = newD; distance = newDist;
-                    invdir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    d = newD; distance = newDist;
+                    ray_set(ray, newO, d);
                     hitRef = -1; hu = 0.0f; hv = 0.0f; redo = false;
                     pa = 0; pb = S - 1; ti = -1;
-                    cur = (ray_box(ts.rootMin[0], ts.rootMin[1], ts.rootMin[2], ts.rootMax[0], ts.rootMax[1], ts.rootMax[2], o, invdir) > 0.0f) ? 0 : kDone;   // WNode 0 is the root's
+                    cur = (ray_box(ts.rootMin[0], ts.rootMin[1], ts.rootMin[2], ts.rootMax[0], ts.rootMax[1], ts.rootMax[2], newO, ray_inv(ray)) > 0.0f) ? 0 : kDone;   // WNode 0 is the root's
                 }
             }
             if (nIdle == 64 && phase == 2) break; // nothing in flight and both queues are exhausted (wave-uniform)
@@ -363,8 +411,8 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
                 if (STATS) { if (kind == 0) tcE.inner++; else tcS.inner++; if (prefix_rank(__ballot(1)) == 0) { if (phase == 0) wInE++; else wInS++; }
                              if ((uint32_t)cur < topCount) { if (kind == 0) topE++; else topS++; }
                              boxes += (uint32_t)ts.wnodes[cur].aux[1]; }
-                const bool h0 = slab_hit(q0.x, q1.x, q2.x, q3.x, q4.x, q5.x, o, invdir), h1 = slab_hit(q0.y, q1.y, q2.y, q3.y, q4.y, q5.y, o, invdir);
-                const bool h2 = slab_hit(q0.z, q1.z, q2.z, q3.z, q4.z, q5.z, o, invdir), h3 = slab_hit(q0.w, q1.w, q2.w, q3.w, q4.w, q5.w, o, invdir);
+                bool h0, h1, h2, h3;
+                slab_hits4(q0, q1, q2, q3, q4, q5, ray, h0, h1, h2, h3);
                 int nxt = kDone;
 #define GMUPT_WIDE_SLOT(H, L) \
                 if (H) { const int l = (L); \
@@ -382,7 +430,7 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
                 if (STATS) { if (kind == 0) tcE.tris++; else tcS.tris++; if (prefix_rank(__ballot(1)) == 0) { if (phase == 0) wTrE++; else wTrS++; } }
                 float t = 0.0f, u = 0.0f, v = 0.0f; bool last;
                 if (tri_compute_flat(make_float4(r0.x, r0.y, r0.z, r0.w), make_float4(r1.x, r1.y, r1.z, r1.w),
-                                     make_float4(r2.x, r2.y, 0.0f, 0.0f), o, d, t, u, v, last)) {
+                                     make_float4(r2.x, r2.y, 0.0f, 0.0f), ray_o(ray), d, t, u, v, last)) {
                     if (kind == 0) {
                         if (t >= 0.0f && t < distance) { distance = t; hitRef = ti; hu = u; hv = v; redo = false; } // extensionRayCast.hlsl:64-74 (a closer hit ends a tie; a full stack ends the walk, so no test follows it)
                         else if (t == distance && hitRef >= 0) { if (tri_canon(rTris, ti) != tri_canon(rTris, hitRef)) redo = true; } // which one the reference keeps depends on its visit order

@@ -225,6 +225,8 @@ struct SbvhBuilder::Impl {
     std::mutex qMutex; std::condition_variable qCond;
     std::vector<Task*> queue;
     int pending = 0;                 // tasks queued or being worked on (under qMutex)
+    std::atomic<int> failAfterTasks{ -1 };   // test hook (GMUPT_SBVH_FAIL_AFTER): the n-th task taken from the queue throws
+    bool stop = false;               // a worker failed: queued tasks are dropped, nobody waits any more (under qMutex)
     std::exception_ptr failure;
     // totals after build
     uint32_t totalNodes = 0, totalRefs = 0, totalDup = 0, maxLevel = 0;
@@ -267,6 +269,7 @@ SbvhBuilder::SbvhBuilder(const float* vertices, uint32_t numVertices, const int3
     int t = env ? std::atoi(env) : (int)(hc ? (hc < 16 ? hc : 16) : 1);   // 16 = the CPU share of one GPU on the target boxes
     m->threads = t < 1 ? 1 : (t > 64 ? 64 : t);
     if (const char* f = std::getenv("GMUPT_BUILD_FANOUT")) m->fanOutFrom = (uint32_t)std::max(2, std::atoi(f));
+    if (const char* f = std::getenv("GMUPT_SBVH_FAIL_AFTER")) m->failAfterTasks = std::atoi(f);   // test hook: the build must fail, not hang
 }
 
 SbvhBuilder::~SbvhBuilder() = default;
@@ -337,7 +340,11 @@ void SbvhBuilder::Impl::buildAll()
 
 void SbvhBuilder::Impl::push(Task* t)
 {
-    { std::lock_guard<std::mutex> g(qMutex); queue.push_back(t); pending++; }
+    {
+        std::lock_guard<std::mutex> g(qMutex);
+        if (stop) { delete t; return; }     // after a failure nothing new is queued (the tree is abandoned)
+        queue.push_back(t); pending++;
+    }
     qCond.notify_one();
 }
 
@@ -348,16 +355,20 @@ void SbvhBuilder::Impl::workerLoop(int wi)
         Task* t = nullptr;
         {
             std::unique_lock<std::mutex> lk(qMutex);
-            qCond.wait(lk, [&]() { return !queue.empty() || pending == 0; });
-            if (queue.empty()) return;              // pending == 0: the tree is complete (or a worker failed)
+            qCond.wait(lk, [&]() { return stop || !queue.empty() || pending == 0; });
+            if (stop || queue.empty()) return;      // a worker failed, or pending == 0: the tree is complete
             t = queue.back(); queue.pop_back();
         }
-        try { finishSubtree(t, w); }
+        try {
+            if (failAfterTasks >= 0 && failAfterTasks-- == 0) { delete t; throw std::runtime_error("sbvh: injected failure (test)"); }
+            finishSubtree(t, w);
+        }
         catch (...) {
-            std::lock_guard<std::mutex> g(qMutex);
-            if (!failure) failure = std::current_exception();
-            for (Task* q : queue) delete q;
-            queue.clear(); pending = 1;             // let every worker leave: the decrement below makes it 0
+            // the first failure wins; every queued task is dropped and every worker -- waiting now or coming back from its task later --
+            // leaves through `stop` (a counter could not say that: workers still inside a task would decrement it below zero)
+            { std::lock_guard<std::mutex> g(qMutex); if (!failure) failure = std::current_exception(); for (Task* q : queue) delete q; queue.clear(); stop = true; }
+            qCond.notify_all();
+            return;
         }
         bool done;
         { std::lock_guard<std::mutex> g(qMutex); done = (--pending == 0); }

@@ -32,18 +32,22 @@ def assemble(tiles, width, height, world_size):
     return frame
 
 
-def gather_tiles(local_tile, width, height, rank, world_size, dist=None, device=None):
+def gather_tiles(local_tile, width, height, rank, world_size, dist=None, device=None, force_collective=False, pad_rows=None):
     """Gathers the per-rank tiles on rank 0.  local_tile: torch tensor (rows, width, 4) float32.
 
     Bands may differ by one row, so every rank pads to the largest band.  Rank 0 returns the assembled frame as a torch tensor
     (height x width x 4) ON THE DEVICE OF THE TILES -- no host copy happens here, the read-back is the caller's business
     (frame.cpu().numpy()); the other ranks return None.
+    A single rank needs no exchange and returns its tile -- unless force_collective is set (the RCCL test: the same gather call on a
+    one-rank nccl group); pad_rows pads every band to at least that many rows (the same test, to run the padded branch there).
     """
     import torch
-    if world_size == 1 or dist is None:
+    if dist is None or (world_size == 1 and not force_collective):
         return local_tile.reshape(height, width, 4)
     bands = row_bands(height, world_size)
     max_rows = max(r for _, r in bands)
+    if pad_rows is not None and pad_rows > max_rows:
+        max_rows = pad_rows
     if local_tile.shape[0] == max_rows:
         padded = local_tile.contiguous()
     else:

@@ -7,6 +7,8 @@ oracle bit for bit through the depth limit.  The tests also assert WHICH ray-cas
 offsets (the arrays stay below its 2 GiB guard) in the instantiation whose traversal stacks spill to global memory (the tree
 is deeper than the LDS part of the stacks).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -26,8 +28,13 @@ def huge_scene(pkg):
 
 def _expect_kernel(pkg, stats, scene):
     capi = pkg.capi
-    assert stats.flags & capi.STAT_FUSED_CAST and stats.flags & capi.STAT_CAST_FETCH, "k_cast_f must be the kernel that ran (flags %#x)" % stats.flags
-    assert scene["depth"] + 2 > 24 and stats.flags & capi.STAT_STACK_SPILL, "depth %d: the spilling instantiation must have run" % scene["depth"]
+    assert stats.flags & capi.STAT_FUSED_CAST, "both ray casts must have run as one launch (flags %#x)" % stats.flags
+    if os.environ.get("GMUPT_TRAVERSAL", "wide") == "wide":
+        # the default: k_cast_w over the 4-wide collapse (128-byte records, 32-bit offsets: the arrays stay below its 2 GiB guard)
+        assert stats.flags & capi.STAT_CAST_WIDE and stats.wide_nodes * 128 < (1 << 31), "k_cast_w must be the kernel that ran (flags %#x)" % stats.flags
+    else:
+        assert stats.flags & capi.STAT_CAST_FETCH, "k_cast_f must be the kernel that ran (flags %#x)" % stats.flags
+        assert scene["depth"] + 2 > 24 and stats.flags & capi.STAT_STACK_SPILL, "depth %d: the spilling instantiation must have run" % scene["depth"]
     assert (stats.flags & capi.STAT_STACK_OVERFLOW) == 0
 
 

@@ -229,3 +229,31 @@ def test_builder_matches_oracle_on_random_small_meshes(pkg, oracle):
         assert np.array_equal(nodes, built["nodes"].view(np.uint8)) and np.array_equal(tris, built["tris"].view(np.uint8))
 
     check()
+
+
+def test_sbvh_build_failure_in_the_task_pool_is_reported_not_hung(pkg, monkeypatch):
+    # a worker that fails while others are inside their tasks (or waiting for one) must end the build with an error: an injected throw at
+    # the n-th queued task, several workers, a mesh big enough to queue tasks.  A counter of pending tasks cannot signal that (workers still
+    # inside a task would decrement it below zero and every waiter would sleep for ever); the pool has a stop flag.
+    import threading
+    mesh = pkg.scenes.random_triangles_mesh(30000, seed=3)
+    monkeypatch.setenv("GMUPT_BUILD_THREADS", "6")
+    result = {}
+
+    def build(fail_after):
+        if fail_after is None:
+            monkeypatch.delenv("GMUPT_SBVH_FAIL_AFTER", raising=False)
+        else:
+            monkeypatch.setenv("GMUPT_SBVH_FAIL_AFTER", str(fail_after))
+        try:
+            result["out"] = pkg.capi.sbvh_build(mesh["verts"], mesh["indices"])
+        except pkg.capi.GmuptError as e:
+            result["out"] = e
+
+    for fail_after in (0, 1, 3):
+        t = threading.Thread(target=build, args=(fail_after,), daemon=True)
+        t.start(); t.join(120)
+        assert not t.is_alive(), "the build hangs after a failure in task %d" % fail_after
+        assert isinstance(result["out"], pkg.capi.GmuptError) and "injected failure" in str(result["out"])
+    build(None)
+    assert isinstance(result["out"], dict) and result["out"]["nodes"].shape[0] > 30000

@@ -74,7 +74,7 @@ def test_two_hip_ranks_render_config4_bands_and_gather(tmp_path, pkg, oracle, cl
         p.join(60)
     for rank, status, info, flags in results:
         assert status == "ok", "rank %d failed:\n%s" % (rank, info)
-        assert flags & pkg.capi.STAT_CAST_FETCH, "rank %d did not run the HIP ray-cast kernel" % rank
+        assert flags & (pkg.capi.STAT_CAST_WIDE | pkg.capi.STAT_CAST_FETCH), "rank %d did not run a fused HIP ray-cast kernel" % rank
     assert all(p.exitcode == 0 for p in procs)
     frame = np.load(out)
     bands = pkg.tiles.row_bands(H, WORLD_OF_CONFIG4)

@@ -19,6 +19,17 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 REL_TOL = 1e-4  # north_star tolerance; the tests below are stricter (bitwise)
 
 
+@pytest.fixture(autouse=True, params=["wide", "cast0"])
+def shipped_kernel(request, monkeypatch):
+    """Every test of this file runs with both shipped fused ray-cast kernels: "wide" (the default: k_cast_w over the 4-wide collapse of the
+    tree) and "cast0" (k_cast_f over the binary tree, which also takes whatever the wide kernel does not).  A test that selects a rung
+    itself overrides the variable."""
+    if request.param != "wide" and any(k in request.node.name for k in ("traversal_rung", "detmath", "shipped_library_has_only", "optin_pruning", "error_convention")):
+        pytest.skip("selects its own kernel, or does not cast rays")
+    monkeypatch.setenv("GMUPT_TRAVERSAL", request.param)
+    return request.param
+
+
 def _assert_same(orc, hip, P, L, it, check_queues=True):
     bad = PU.compare_state(orc, hip, P, L)
     assert not bad, "iteration %d: path state differs: %r" % (it, bad[:4])
@@ -73,7 +84,7 @@ def test_iteration_parity(pkg, device, cornell_scene, soup_scene, spheres_small_
     hip.close(); sb.close(); orc.close()
 
 
-@pytest.mark.parametrize("mode", ["ref", "static", "whilewhile", "ifif1", "top", "coop", "def0", "def1", "pipe0", "cast0", "cast1", "cast2", "cast3"])
+@pytest.mark.parametrize("mode", ["ref", "static", "whilewhile", "ifif1", "top", "coop", "def0", "def1", "pipe0", "cast0", "cast1", "cast2", "cast3", "wide"])
 def test_every_traversal_rung_gives_the_same_bits(pkg, soup_scene, monkeypatch, mode):
     # the ladder of ray-cast kernels kept for A/B timing (GMUPT_TRAVERSAL): every rung against the oracle.
     # The rungs are only part of the -DGMUPT_VARIANTS test build of the library (libgmupt_variants.so); the shipped one has cast0 + def0.
@@ -194,7 +205,7 @@ def test_russian_roulette_branch_is_exercised(pkg, device, spheres_small_scene):
     hip.close(); sb.close(); orc.close()
 
 
-def test_traversal_statistics_match(pkg, device, soup_scene):
+def test_traversal_statistics_match(pkg, device, soup_scene, shipped_kernel):
     # the counting variant of the ray-cast kernels reports the same inner-node / triangle-test totals as the oracle for the
     # extension stage (the visited set does not depend on the traversal order)
     W, H, P = 32, 18, 1024
@@ -203,7 +214,13 @@ def test_traversal_statistics_match(pkg, device, soup_scene):
         PU.step_both(orc, hip, ocam, hcam)
     _assert_same(orc, hip, P, P, 9)
     so, sh = orc.stats(), hip.stats()
-    assert (so.extRays, so.extInner, so.extLeaves, so.extTris) == (sh.ext_rays, sh.ext_inner, sh.ext_leaves, sh.ext_tris)
+    if shipped_kernel == "wide":
+        # the wide walk reaches the same leaves and makes the same triangle tests through about half as many (4-wide) nodes; a ray that was
+        # walked again in the reference's order (an exact tie) is not counted a second time
+        assert sh.flags & pkg.capi.STAT_CAST_WIDE and sh.wide_nodes > 0 and sh.wide_box_tests > 0
+        assert (so.extRays, so.extLeaves, so.extTris) == (sh.ext_rays, sh.ext_leaves, sh.ext_tris) and 0 < sh.ext_inner < 0.7 * so.extInner
+    else:
+        assert (so.extRays, so.extInner, so.extLeaves, so.extTris) == (sh.ext_rays, sh.ext_inner, sh.ext_leaves, sh.ext_tris)
     # the any-hit shadow ray is free in how far it walks (deferred triangle tests walk further, skipping boxes entered beyond the
     # light walks less): only the number of rays and -- through _assert_same above -- every inShadow bit must agree
     assert so.shRays == sh.sh_rays and sh.sh_inner > 0 and sh.sh_tris > 0
@@ -393,6 +410,60 @@ def test_ray_casts_on_grid_meshes_with_exact_ties(pkg, device, seed):
     hip.close(); sb.close(); orc.close()
 
 
+def _grid_mesh(pkg, rng, n_tris, grid, name):
+    nv = max(4, n_tris // 2)
+    verts = (rng.integers(0, grid, (nv, 3)) * (8.0 / (grid - 1)) - 4.0).astype(np.float32)
+    idx = rng.integers(0, nv, (n_tris, 3)).astype(np.int32)
+    idx[: n_tris // 5] = idx[n_tris // 5: 2 * (n_tris // 5)][: n_tris // 5]          # exact duplicates of other triangles
+    mesh = pkg.scenes.cornell_mesh()
+    mesh.update({"verts": verts, "normals": np.tile(np.array([0.0, 1.0, 0.0], np.float32), (nv, 1)), "indices": idx,
+                 "vertex_material": (rng.integers(0, 3, nv)).astype(np.uint32), "name": name})
+    mesh.pop("uv", None)
+    return mesh
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_drain_protocol_on_tie_meshes(pkg, device, monkeypatch, shipped_kernel, seed):
+    # The hand-over protocol of the drain, directed: 64-ray chunks on a launch of 8192 rays of either kind put every wave that gets work
+    # into the drain after its first refill; a few thousand coplanar / duplicated triangles on a coarse grid make long walks (deep stacks to
+    # give away) AND exact ties in t, which is where the merge rules decide pixels -- k_cast_f: a helper's hit counts only if strictly closer
+    # than the owner's, among helpers the later donation wins a tie (`dh > dT`); k_cast_w: equal t between lanes sends the ray to the exact
+    # walk.  Asserted: subtrees were given away, helpers gave parts of theirs away in turn (two levels), and every extension AND shadow
+    # result equals the oracle's bit for bit.
+    monkeypatch.setenv("GMUPT_RAYS_PER_WAVE", "64")
+    rng = np.random.default_rng(seed)
+    scene = pkg.scenes.build_scene(_grid_mesh(pkg, rng, 3000, 9, "drain%d" % seed))
+    P = 8192
+    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, scene, 32, 18, P, collect_stats=True, threads=16)
+    pts = (rng.integers(0, 9, (P, 3)) - 4.0).astype(np.float32)
+    dirs = rng.choice(np.array([-2.0, -1.0, -0.5, 0.5, 1.0, 2.0], np.float32), (P, 3))
+    dirs[::4] = rng.integers(-2, 3, (P // 4 + (P % 4 > 0), 3)).astype(np.float32)[: len(dirs[::4])]     # a quarter with zero components as well
+    dirs[(dirs == 0).all(axis=1)] = (1.0, 0.0, 0.0)
+    o = (pts - dirs * rng.integers(1, 4, (P, 1)).astype(np.float32)).astype(np.float32)
+    st = orc.path_state()
+    O.state_field(st, P, "rayOrigin").view(np.float32)[:] = o; O.state_field(st, P, "rayDirection").view(np.float32)[:] = dirs
+    O.state_field(st, P, "shadowrayOrigin").view(np.float32)[:] = o; O.state_field(st, P, "shadowrayDirection").view(np.float32)[:] = dirs
+    O.state_field(st, P, "lightDistance").view(np.float32)[:, 0] = rng.uniform(0.5, 12.0, P).astype(np.float32)
+    orc.queues()[3][:] = np.arange(P, dtype=np.uint32); orc.queues()[4][:] = np.arange(P, dtype=np.uint32)[::-1]
+    qc = orc.counters(); qc[:] = 0; qc[6] = P; qc[7] = P
+    ocam.update(); hcam.update(0.0); orc.set_camera(ocam.buffer); hip.set_camera(hcam.buffer)
+    frozen = (orc.path_state().copy(), orc.queues().copy(), orc.counters().copy())
+    orc.stage("extension"); orc.stage("shadow")
+    hits = O.state_field(orc.path_state(), P, "hitDistance").view(np.float32)[:, 0]
+    occluded = O.state_field(orc.path_state(), P, "inShadow")[:, 0]
+    assert (hits < 3e38).sum() > P // 4 and 0 < int((occluded != 0).sum()) < P
+    hip.write_path_state(frozen[0]); hip.write_queues(frozen[1]); hip.write_counters(frozen[2])
+    hip.run_stage(pkg.capi.STAGE_RAYCASTS)
+    bad = PU.compare_state(orc, hip, P, P, fields=["surfacePoint", "baryCoord", "triangle", "isEmitter", "hitDistance", "inShadow"])
+    assert not bad, bad[:3]
+    sh = hip.stats()
+    assert sh.flags & pkg.capi.STAT_FUSED_CAST
+    assert sh.cast_helper_subtrees > 0, "no subtree was handed to a free lane"
+    assert sh.cast_nested_helpers > 0, "no helper gave a part of its subtree away (two-level donation)"
+    print("%s seed %d: %d subtrees given, %d of them by helpers, %d rays walked again" % (shipped_kernel, seed, sh.cast_helper_subtrees, sh.cast_nested_helpers, sh.cast_redo_rays))
+    hip.close(); sb.close(); orc.close()
+
+
 def test_camera_reset_resize_and_light_update(pkg, device, cornell_scene):
     W, H, P = 32, 18, 1024
     orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, cornell_scene, W, H, P)
@@ -457,10 +528,8 @@ def test_ray_cast_watchdog_ends_the_launch_and_flags_it(pkg, device, spheres_sma
             call()
         assert e.value.code == capi.ERR_CAST_FAULT
     assert r.stats(check=False).flags & capi.STAT_CAST_ABORTED
-    import torch
-    dst = torch.empty((54, 96, 4), dtype=torch.float32, device="cuda")
-    with pytest.raises(capi.GmuptError, match="invalid"):
-        r.copy_framebuffer_to_device(dst.data_ptr(), dst.numel() * 4)
+    # (gmupt_copy_framebuffer_to_device makes the same check; it needs a device pointer from torch, which must be the first HIP user of
+    #  its process: tests/test_rccl_gpu.py covers it)
     r.reset_stats()                      # the flag is sticky until the statistics are reset
     r.synchronize()
     r.close()

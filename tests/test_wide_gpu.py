@@ -20,28 +20,6 @@ def wide(monkeypatch):
     monkeypatch.setenv("GMUPT_TRAVERSAL", "wide")
 
 
-@pytest.mark.parametrize("scene_name,W,H,P,L,iters", [
-    ("cornell", 64, 36, 4096, 0, 30),
-    ("cornell", 32, 18, 8192, 6144, 12),
-    ("soup", 48, 27, 2048, 0, 40),
-    ("spheres", 48, 27, 2048, 0, 120),
-    ("textured", 48, 27, 2048, 0, 40),
-])
-def test_wide_iteration_parity(pkg, device, wide, cornell_scene, soup_scene, spheres_small_scene, scene_name, W, H, P, L, iters):
-    scene = {"cornell": cornell_scene, "soup": soup_scene, "spheres": spheres_small_scene}[scene_name] if scene_name != "textured" \
-        else pkg.scenes.build_scene(pkg.scenes.textured_mesh())
-    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, scene, W, H, P, live=L)
-    live = L or P
-    for it in range(iters):
-        PU.step_both(orc, hip, ocam, hcam)
-        if it < 6 or it % 10 == 9 or it == iters - 1:
-            _assert_same(orc, hip, P, live, it)
-    sh = hip.stats()
-    assert sh.flags & pkg.capi.STAT_CAST_WIDE, "the wide kernel did not run"
-    assert not (sh.flags & (pkg.capi.STAT_STACK_OVERFLOW | pkg.capi.STAT_CAST_ABORTED))
-    hip.close(); sb.close(); orc.close()
-
-
 def test_wide_statistics(pkg, device, wide, soup_scene):
     # leaves reached and triangles tested by the extension rays are the reference's (the visited set does not depend on the order or on
     # which ancestors are tested); the wide nodes visited are about half the binary inner nodes
@@ -146,33 +124,6 @@ def test_wide_ties_without_zero_components(pkg, device, wide):
     assert not bad, bad[:3]
     sh = hip.stats()
     assert sh.cast_redo_rays > P // 8, "the coplanar squares tie on every ray that hits them: %d redo rays" % sh.cast_redo_rays
-    hip.close(); sb.close(); orc.close()
-
-
-def test_wide_deep_tree(pkg, device, wide):
-    scene = pkg.scenes.build_scene(pkg.scenes.deep_chain_mesh())
-    W, H, P = 48, 32, 2048
-    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, scene, W, H, P)
-    for it in range(12):
-        PU.step_both(orc, hip, ocam, hcam)
-        _assert_same(orc, hip, P, P, it)
-    sh = hip.stats()
-    assert sh.flags & pkg.capi.STAT_CAST_WIDE and not (sh.flags & pkg.capi.STAT_STACK_OVERFLOW)
-    hip.close(); sb.close(); orc.close()
-
-
-@pytest.mark.parametrize("knobs", [
-    {"GMUPT_RAYS_PER_WAVE": "64", "GMUPT_REFILL": "1", "GMUPT_TRI_THRESH": "1", "GMUPT_WAVES_PER_CU": "4"},
-    {"GMUPT_RAYS_PER_WAVE": "128", "GMUPT_REFILL": "64", "GMUPT_TRI_THRESH": "64", "GMUPT_WAVES_PER_CU": "16"},
-], ids=["eager", "lazy"])
-def test_wide_results_do_not_depend_on_scheduling_knobs(pkg, device, wide, spheres_small_scene, monkeypatch, knobs):
-    for k, v in knobs.items():
-        monkeypatch.setenv(k, v)
-    W, H, P = 48, 27, 4096
-    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, spheres_small_scene, W, H, P)
-    for it in range(16):
-        PU.step_both(orc, hip, ocam, hcam)
-    _assert_same(orc, hip, P, P, 16)
     hip.close(); sb.close(); orc.close()
 
 

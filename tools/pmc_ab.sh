@@ -6,7 +6,7 @@ MODE=${1:?mode}
 export GMUPT_TRAVERSAL=$MODE
 OUT=gpurun_out/pmc_$MODE
 rm -rf $OUT; mkdir -p $OUT
-CMD="python3 bench.py --no-cpu-baseline --no-roofline --no-full-frame --prewarm 260 --steps 20 --warmup 5"
+CMD="python3 bench.py --no-cpu-baseline --no-roofline --no-full-frame --no-config5 --prewarm 260 --steps 20 --warmup 5"
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAVES" \
            "SQ_INSTS_VMEM_RD SQ_INST_LEVEL_VMEM SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR" \

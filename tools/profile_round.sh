@@ -18,7 +18,7 @@ if [ "$MODE" = config5 ]; then
 else
   timeout -k 10 500 python3 bench.py > $OUT/run.log 2>&1 || { echo "plain run failed"; tail -5 $OUT/run.log; exit 1; }
   tail -1 $OUT/run.log > $OUT/run.json
-  CMD="python3 bench.py --no-cpu-baseline --no-roofline --no-full-frame"; SHORT="--prewarm 260 --steps 20 --warmup 5"; SKIP=265
+  CMD="python3 bench.py --no-cpu-baseline --no-roofline --no-full-frame --no-config5"; SHORT="--prewarm 260 --steps 20 --warmup 5"; SKIP=265
 fi
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1 || { echo "trace pass failed"; tail -5 $OUT/trace.log; exit 1; }
 cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv
