@@ -256,4 +256,4 @@ def test_sbvh_build_failure_in_the_task_pool_is_reported_not_hung(pkg, monkeypat
         assert not t.is_alive(), "the build hangs after a failure in task %d" % fail_after
         assert isinstance(result["out"], pkg.capi.GmuptError) and "injected failure" in str(result["out"])
     build(None)
-    assert isinstance(result["out"], dict) and result["out"]["nodes"].shape[0] > 30000
+    assert isinstance(result["out"], dict) and result["out"]["nodes"].shape[0] > 10000 and result["out"]["tris"].shape[0] >= 30000
