@@ -26,9 +26,7 @@ FLAGS = [
 # and a build of the wide ray cast whose stacks overflow on ordinary scenes.
 TEST_BUILDS = {"variants": ["-DGMUPT_VARIANTS"], "scan1": ["-DGMUPT_SCAN_GROUP=1"],
                "wides8": ["-DGMUPT_WIDE_STACK=8", "-DGMUPT_WIDE_TOP=64", "-DGMUPT_WIDE_PARK=4"]}   # wide ray cast with a tiny LDS share per lane: stacks run full, rays are parked for the exact walk all the time
-EXPERIMENT_BUILDS = {"wpk0": ["-DGMUPT_WIDE_PK=0"], "wr6": ["-DGMUPT_WIDE_REPS=6"], "wr3": ["-DGMUPT_WIDE_REPS=3"], "ws20": ["-DGMUPT_WIDE_STACK=20", "-DGMUPT_WIDE_TOP=640"],
-                     "ws20r6": ["-DGMUPT_WIDE_STACK=20", "-DGMUPT_WIDE_TOP=640", "-DGMUPT_WIDE_REPS=6"], "ws16r6": ["-DGMUPT_WIDE_STACK=16", "-DGMUPT_WIDE_TOP=768", "-DGMUPT_WIDE_REPS=6"],
-                     "ws24r6": ["-DGMUPT_WIDE_STACK=24", "-DGMUPT_WIDE_TOP=512", "-DGMUPT_WIDE_REPS=6"]}   # name -> extra flags of A/B timing builds (tools/ only, never loaded by tests), e.g. {"wg1024": ["-DGMUPT_DEF_BLOCK=1024", "-DGMUPT_TOP_NODES=512"]}
+EXPERIMENT_BUILDS = {}   # name -> extra flags of A/B timing builds (tools/ only, never loaded by tests), e.g. {"wg1024": ["-DGMUPT_DEF_BLOCK=1024", "-DGMUPT_TOP_NODES=512"]}
 
 
 def lib_path(name=None):

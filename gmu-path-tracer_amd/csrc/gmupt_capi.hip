@@ -213,7 +213,7 @@ struct gmupt_renderer {
     double msStage[4] = { 0, 0, 0, 0 }; uint64_t timedIters = 0;
     std::vector<void*> allocs;
     // packed traversal copy of the bound scene
-    void* travNodes = nullptr; void* travTris = nullptr; void* travRecs = nullptr; void* travWide = nullptr;
+    void* travNodes = nullptr; void* travTris = nullptr; void* travRecs = nullptr; void* travWide = nullptr; void* travPairs = nullptr; void* travPairRef = nullptr;
     int travMode = 70; // GMUPT_TRAVERSAL: "wide" (default) both ray casts in one launch over the 4-wide collapse | "cast0" the same over the binary tree | "def0" separate launches; the other rungs of the ladder exist in -DGMUPT_VARIANTS builds only
     uint32_t castFlags = 0; // GMUPT_STAT_* bits of the ray-cast kernels launched since the last reset
 };
@@ -252,6 +252,8 @@ extern "C" void gmupt_renderer_destroy(gmupt_renderer* r)
     if (r->travTris) (void)hipFree(r->travTris);
     if (r->travRecs) (void)hipFree(r->travRecs);
     if (r->travWide) (void)hipFree(r->travWide);
+    if (r->travPairs) (void)hipFree(r->travPairs);
+    if (r->travPairRef) (void)hipFree(r->travPairRef);
     if (r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
 }
@@ -494,6 +496,34 @@ static int build_traversal_copy(gmupt_renderer* r, const gmupt_buffer* nodesB, c
     // 4-wide collapse (WNode, pt_device.hpp): the two children of an inner node, the inner one with the largest surface area replaced by
     // ITS children until four slots are taken; every inner slot becomes a wide node in turn.  Only built when every child box lies inside
     // its parent's box (what a bounding-volume hierarchy is; the wide walk's equivalence to the binary one rests on it).
+    // the leaves as triangle pairs (TriPair, pt_device.hpp): consecutive references of a leaf two by two
+    std::vector<TriPair> pairs;
+    std::vector<uint32_t> pairRef;
+    std::vector<int32_t> leafPair(N, -1);       // first pair of every leaf node
+    if (wantWide) {
+        pairs.reserve(R / 2 + N / 2 + 2); pairRef.reserve(R + N + 4);
+        auto put = [&](TriPair& pr, int slot, size_t ref) {
+            const Tri48& t = ptris[ref];
+            const float c[9] = { t.r0[0], t.r0[1], t.r0[2], t.r0[3], t.r1[0], t.r1[1], t.r1[2], t.r1[3], t.r2[0] };   // v0.xyz, e1.xyz, e2.xyz
+            for (int k = 0; k < 9; k++) pr.w[2 * k + slot] = c[k];
+        };
+        const uint32_t one32 = 1u;
+        for (size_t i = 0; i < N; i++) {
+            if (!nodes[i].isLeaf) continue;
+            leafPair[i] = (int32_t)pairs.size();
+            const int32_t a = nodes[i].left, b = nodes[i].right;
+            for (int32_t k = a; k < b || k == a; k += 2) {          // (an empty leaf gets one all-zero pair)
+                TriPair pr; std::memset(&pr, 0, sizeof(pr));
+                uint32_t r0 = 0xFFFFFFFFu, r1 = 0xFFFFFFFFu;
+                if (k < b) { put(pr, 0, (size_t)k); r0 = (uint32_t)k; }
+                if (k + 1 < b) { put(pr, 1, (size_t)k + 1); r1 = (uint32_t)k + 1; }
+                if (k + 2 >= b) std::memcpy(&pr.w[18], &one32, 4);
+                const uint32_t nrefs = (k < b ? 1u : 0u) + (k + 1 < b ? 1u : 0u); std::memcpy(&pr.w[19], &nrefs, 4);   // (statistics)
+                pairs.push_back(pr); pairRef.push_back(r0); pairRef.push_back(r1);
+            }
+        }
+    }
+
     std::vector<WNode> wide;
     uint32_t wideTop = 0, wideBound = 0;
     bool contained = true;
@@ -565,7 +595,7 @@ static int build_traversal_copy(gmupt_renderer* r, const gmupt_buffer* nodesB, c
                 if (k < w.n) {
                     const gmupt_bvh_node& b = nodes[(size_t)w.s[k]];
                     for (int a = 0; a < 3; a++) { o.p[a][k] = b.min[a]; o.p[3 + a][k] = b.max[a]; }
-                    o.link[k] = b.isLeaf ? desc(w.s[k]) : number[(size_t)createdOf[(size_t)w.s[k]]];
+                    o.link[k] = b.isLeaf ? ~leafPair[(size_t)w.s[k]] : number[(size_t)createdOf[(size_t)w.s[k]]];
                 } else {
                     for (int a = 0; a < 6; a++) o.p[a][k] = qnan;      // never hit
                     o.link[k] = (int32_t)0x80000000;
@@ -588,6 +618,15 @@ static int build_traversal_copy(gmupt_renderer* r, const gmupt_buffer* nodesB, c
         HIP_TRY(hipMalloc(&r->travWide, wide.size() * sizeof(WNode)));
         HIP_TRY(hipMemcpy(r->travWide, wide.data(), wide.size() * sizeof(WNode), hipMemcpyHostToDevice));
     }
+    if (r->travPairs) { HIP_TRY(hipFree(r->travPairs)); r->travPairs = nullptr; }
+    if (r->travPairRef) { HIP_TRY(hipFree(r->travPairRef)); r->travPairRef = nullptr; }
+    if (!wide.empty()) {
+        HIP_TRY(hipMalloc(&r->travPairs, pairs.size() * sizeof(TriPair)));
+        HIP_TRY(hipMemcpy(r->travPairs, pairs.data(), pairs.size() * sizeof(TriPair), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&r->travPairRef, pairRef.size() * 4));
+        HIP_TRY(hipMemcpy(r->travPairRef, pairRef.data(), pairRef.size() * 4, hipMemcpyHostToDevice));
+    }
+    r->p.trav.pairs = (const TriPair*)r->travPairs; r->p.trav.pairRef = (const uint32_t*)r->travPairRef; r->p.trav.numPairs = (uint32_t)pairs.size();
     r->p.trav.wnodes = (const WNode*)r->travWide; r->p.trav.wideCount = (uint32_t)wide.size(); r->p.trav.wideTopCount = wideTop; r->p.trav.wideStackBound = wideBound;
     r->p.trav.wideRootDesc = 0;
 

@@ -104,6 +104,13 @@ static_assert(sizeof(Node64) == 64 && sizeof(Tri48) == 48, "packed traversal rec
 struct alignas(128) WNode { float p[6][4]; int32_t link[4]; int32_t aux[4]; };
 static_assert(sizeof(WNode) == 128, "one wide node per 128-byte line");
 
+// TriPair: TWO references of one leaf, component by component, for the wide kernel's packed triangle test (two triangles per step on
+// v_pk_* arithmetic): w[2c], w[2c + 1] = component c of the first / second triangle in the order v0.xyz, e1.xyz, e2.xyz (18 words), then
+// w[18] != 0 on the last pair of the leaf, w[19] spare.  A leaf with an odd number of references ends with an all-zero second triangle
+// (det = 0: rejected by the test itself).  pairRef[2 p + k] = the reference (index of the Tri48 / gmupt_triangle record) in slot k of pair p.
+struct alignas(16) TriPair { float w[20]; };
+static_assert(sizeof(TriPair) == 80, "packed triangle pairs");
+
 // Rec64: the same data as 64-byte records in ONE array (inner nodes first, then one record per triangle reference) for the
 // cooperative ray-cast kernels: a lane needs exactly one record per step, and four adjacent lanes fetch the four 16-byte
 // quarters of one record with a single LDS-DMA instruction.  Triangle record: r0..r2 as Tri48, r3 = (v0, v1, v2, materialID).
@@ -134,6 +141,9 @@ struct TravScene {
     uint32_t wideTopCount;   // wnodes[0 .. wideTopCount) live in LDS (largest surface area first)
     uint32_t wideStackBound; // entries the walk of this tree can have pending at most (all four slots hit on every level)
     int32_t wideRootDesc;    // 0 (the root's WNode) or the leaf descriptor of a one-leaf tree
+    const TriPair* pairs;    // the leaves of the wide tree as triangle pairs (a leaf link of a WNode is ~first pair)
+    const uint32_t* pairRef; // 2 per pair: the reference in that slot, 0xFFFFFFFF in a padding slot
+    uint32_t numPairs;
 };
 
 struct RenderParams {

@@ -53,26 +53,22 @@ constexpr int kWideOvf = kMaxStack + 2 > kWideStack ? kMaxStack + 2 - kWideStack
 
 typedef int vec4i __attribute__((ext_vector_type(4)));
 
-// One WNode into registers: the LDS lanes first, then the global lanes (see load_node in pt_traverse_deferred.hpp)
-__device__ __forceinline__ void load_wnode(__amdgpu_buffer_rsrc_t nodes, const float4* s_top, uint32_t topCount, int cur,
-                                           vec4f& q0, vec4f& q1, vec4f& q2, vec4f& q3, vec4f& q4, vec4f& q5, vec4i& lk)
+// One WNode into registers: from the LDS copy of the tree top (the top walk), or from global memory (everything below the top)
+__device__ __forceinline__ void load_wnode_lds(const float4* s_top, int cur, vec4f& q0, vec4f& q1, vec4f& q2, vec4f& q3, vec4f& q4, vec4f& q5, vec4i& lk)
 {
-    const bool inTop = (uint32_t)cur < topCount;
-    if (inTop) {
-        const GMUPT_AS_LDS vec4f* n = (const GMUPT_AS_LDS vec4f*)(s_top) + cur * 8;
-        q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = n[3]; q4 = n[4]; q5 = n[5]; lk = *(const GMUPT_AS_LDS vec4i*)(n + 6);
-    }
-    asm volatile("" ::: "memory");
-    if (!inTop) {
-        const int off = cur * 128;
-        q0 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off, 0, 0));
-        q1 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 16, 0, 0));
-        q2 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 32, 0, 0));
-        q3 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 48, 0, 0));
-        q4 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 64, 0, 0));
-        q5 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 80, 0, 0));
-        lk = __builtin_bit_cast(vec4i, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 96, 0, 0));
-    }
+    const GMUPT_AS_LDS vec4f* n = (const GMUPT_AS_LDS vec4f*)(s_top) + cur * 8;
+    q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = n[3]; q4 = n[4]; q5 = n[5]; lk = *(const GMUPT_AS_LDS vec4i*)(n + 6);
+}
+__device__ __forceinline__ void load_wnode_glb(__amdgpu_buffer_rsrc_t nodes, int cur, vec4f& q0, vec4f& q1, vec4f& q2, vec4f& q3, vec4f& q4, vec4f& q5, vec4i& lk)
+{
+    const int off = cur * 128;
+    q0 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off, 0, 0));
+    q1 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 16, 0, 0));
+    q2 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 32, 0, 0));
+    q3 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 48, 0, 0));
+    q4 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 64, 0, 0));
+    q5 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 80, 0, 0));
+    lk = __builtin_bit_cast(vec4i, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 96, 0, 0));
 }
 
 // the slab test of ray_box (extensionRayCast.hlsl:79-94) on one slot; "hit" is `result > 0`, i.e. t1 >= t0 and (t0 > 0 ? t0 : t1) > 0,
@@ -92,44 +88,64 @@ __device__ __forceinline__ uint32_t tri_canon(__amdgpu_buffer_rsrc_t tris, int i
     return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(tris, i * 48 + 40, 0, 0);
 }
 
-// The four slab tests of a step on packed binary32 arithmetic: (plane - o) * (1 / d) for two slots per v_pk_add_f32 / v_pk_mul_f32 -- the
-// same IEEE operations on the same operands as the scalar form, two at a time -- and the min / max tree as the machine instructions
-// themselves.  (Written with __builtin_fminf the compiler puts a canonicalising v_max x, x in front of every product of a packed
-// multiply -- 24 extra instructions per step; v_min / v_max / v_min3 / v_max3 return the non-NaN operand like the HLSL min / max, and
-// no operand here can be a signalling NaN: products and the quiet NaNs of empty slots.)
+// Packed binary32 arithmetic (v_pk_add_f32 / v_pk_mul_f32: the same IEEE operations as the scalar instructions, two at a time) as the
+// machine instructions themselves.  Why not vector types and the compiler: (1) it puts a canonicalising `v_max x, x` in front of every
+// fminf / fmaxf that consumes a packed product; (2) a scalar operand that both halves must see (a ray component) it either copies into
+// a register pair of its own -- 18 registers this kernel does not have -- or re-aligns through SCRATCH memory in every step; the
+// instruction itself can take either half of an aligned pair for both results (op_sel).  So the ray lives in five aligned pairs (RayPk)
+// and each helper names the half it broadcasts.  Every packed instruction is followed by `s_nop 0`: on gfx950 its result may not be read
+// by the very next instruction (the compiler pads its own packed code the same way; it cannot see into an asm statement).
+// v_min / v_max / v_min3 / v_max3 return the non-NaN operand like the HLSL min / max, and no operand here can be a signalling NaN
+// (products, and the quiet NaNs of empty slots).
 #ifndef GMUPT_WIDE_PK
 #define GMUPT_WIDE_PK 1
 #endif
+#define GMUPT_PK2(NAME, TEXT) __device__ __forceinline__ vec2f NAME(vec2f a, vec2f b) { vec2f r; asm(TEXT "\n\ts_nop 0" : "=v"(r) : "v"(a), "v"(b)); return r; }
+GMUPT_PK2(pk_mul, "v_pk_mul_f32 %0, %1, %2")                                                        // a * b
+GMUPT_PK2(pk_add, "v_pk_add_f32 %0, %1, %2")                                                        // a + b
+GMUPT_PK2(pk_sub, "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]")                              // a - b
+GMUPT_PK2(pk_mul_lo, "v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]")                                     // a * (b.x, b.x)
+GMUPT_PK2(pk_mul_hi, "v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]")                                        // a * (b.y, b.y)
+GMUPT_PK2(pk_sub_lo, "v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]")           // a - (b.x, b.x)
+GMUPT_PK2(pk_sub_hi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]")              // a - (b.y, b.y)
+GMUPT_PK2(pk_lo_sub, "v_pk_add_f32 %0, %2, %1 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]")           // (b.x, b.x) - a
+GMUPT_PK2(pk_hi_sub, "v_pk_add_f32 %0, %2, %1 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]")              // (b.y, b.y) - a
+#undef GMUPT_PK2
 __device__ __forceinline__ float v_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float v_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float v_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float v_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+// The lane's ray in five aligned register pairs: (o.x, o.y), (o.z, 1/d.z), (1/d.x, 1/d.y), (d.x, d.y), (d.z, -)
+struct RayPk { vec2f oxy, ozi, ixy, dxy, dzz; };
+__device__ __forceinline__ f3 ray_o(const RayPk& r) { return mk3(r.oxy.x, r.oxy.y, r.ozi.x); }
+__device__ __forceinline__ f3 ray_inv(const RayPk& r) { return mk3(r.ixy.x, r.ixy.y, r.ozi.y); }
+__device__ __forceinline__ f3 ray_d(const RayPk& r) { return mk3(r.dxy.x, r.dxy.y, r.dzz.x); }
+__device__ __forceinline__ void ray_set(RayPk& r, f3 o, f3 d)
+{
+    r.oxy.x = o.x; r.oxy.y = o.y; r.ozi.x = o.z; r.ixy.x = 1.0f / d.x; r.ixy.y = 1.0f / d.y; r.ozi.y = 1.0f / d.z;
+    r.dxy.x = d.x; r.dxy.y = d.y; r.dzz.x = d.z; r.dzz.y = 0.0f;
+}
+
+#define GMUPT_LO(Q) __builtin_shufflevector(Q, Q, 0, 1)
+#define GMUPT_HI(Q) __builtin_shufflevector(Q, Q, 2, 3)
 __device__ __forceinline__ bool slab_hit_pk(float nx, float ny, float nz, float fx, float fy, float fz)
 {
     const float t1 = v_min3(v_max(fx, nx), v_max(fy, ny), v_max(fz, nz));
     const float t0 = v_max3(v_min(fx, nx), v_min(fy, ny), v_min(fz, nz));
     return (t1 >= t0) & (t1 > 0.0f);
 }
-// The ray's origin and 1 / d live in three register PAIRS -- (o.x, o.y), (1/d.x, 1/d.y), (o.z, 1/d.z) -- so that every packed instruction
-// takes its broadcast operand from one half of an aligned pair (op_sel) without a copy.
-struct RayPk { vec2f oxy, ixy, ozi; };
-__device__ __forceinline__ f3 ray_o(const RayPk& r) { return mk3(r.oxy.x, r.oxy.y, r.ozi.x); }
-__device__ __forceinline__ f3 ray_inv(const RayPk& r) { return mk3(r.ixy.x, r.ixy.y, r.ozi.y); }
-__device__ __forceinline__ void ray_set(RayPk& r, f3 o, f3 d) { r.oxy.x = o.x; r.oxy.y = o.y; r.ozi.x = o.z; r.ixy.x = 1.0f / d.x; r.ixy.y = 1.0f / d.y; r.ozi.y = 1.0f / d.z; }
-
+// the four slab tests of a step: (plane - o) * (1 / d) for two slots per packed instruction, then the min / max tree of ray_box per slot
 __device__ __forceinline__ void slab_hits4(const vec4f q0, const vec4f q1, const vec4f q2, const vec4f q3, const vec4f q4, const vec4f q5, const RayPk& ray,
                                            bool& h0, bool& h1, bool& h2, bool& h3)
 {
 #if GMUPT_WIDE_PK
-    const vec2f ox = __builtin_shufflevector(ray.oxy, ray.oxy, 0, 0), oy = __builtin_shufflevector(ray.oxy, ray.oxy, 1, 1), oz = __builtin_shufflevector(ray.ozi, ray.ozi, 0, 0);
-    const vec2f ix = __builtin_shufflevector(ray.ixy, ray.ixy, 0, 0), iy = __builtin_shufflevector(ray.ixy, ray.ixy, 1, 1), iz = __builtin_shufflevector(ray.ozi, ray.ozi, 1, 1);
-#define GMUPT_LO(Q) __builtin_shufflevector(Q, Q, 0, 1)
-#define GMUPT_HI(Q) __builtin_shufflevector(Q, Q, 2, 3)
-    const vec2f nxa = (GMUPT_LO(q0) - ox) * ix, nxb = (GMUPT_HI(q0) - ox) * ix, nya = (GMUPT_LO(q1) - oy) * iy, nyb = (GMUPT_HI(q1) - oy) * iy;
-    const vec2f nza = (GMUPT_LO(q2) - oz) * iz, nzb = (GMUPT_HI(q2) - oz) * iz, fxa = (GMUPT_LO(q3) - ox) * ix, fxb = (GMUPT_HI(q3) - ox) * ix;
-    const vec2f fya = (GMUPT_LO(q4) - oy) * iy, fyb = (GMUPT_HI(q4) - oy) * iy, fza = (GMUPT_LO(q5) - oz) * iz, fzb = (GMUPT_HI(q5) - oz) * iz;
-#undef GMUPT_LO
-#undef GMUPT_HI
+    const vec2f nxa = pk_mul_lo(pk_sub_lo(GMUPT_LO(q0), ray.oxy), ray.ixy), nxb = pk_mul_lo(pk_sub_lo(GMUPT_HI(q0), ray.oxy), ray.ixy);
+    const vec2f nya = pk_mul_hi(pk_sub_hi(GMUPT_LO(q1), ray.oxy), ray.ixy), nyb = pk_mul_hi(pk_sub_hi(GMUPT_HI(q1), ray.oxy), ray.ixy);
+    const vec2f nza = pk_mul_hi(pk_sub_lo(GMUPT_LO(q2), ray.ozi), ray.ozi), nzb = pk_mul_hi(pk_sub_lo(GMUPT_HI(q2), ray.ozi), ray.ozi);
+    const vec2f fxa = pk_mul_lo(pk_sub_lo(GMUPT_LO(q3), ray.oxy), ray.ixy), fxb = pk_mul_lo(pk_sub_lo(GMUPT_HI(q3), ray.oxy), ray.ixy);
+    const vec2f fya = pk_mul_hi(pk_sub_hi(GMUPT_LO(q4), ray.oxy), ray.ixy), fyb = pk_mul_hi(pk_sub_hi(GMUPT_HI(q4), ray.oxy), ray.ixy);
+    const vec2f fza = pk_mul_hi(pk_sub_lo(GMUPT_LO(q5), ray.ozi), ray.ozi), fzb = pk_mul_hi(pk_sub_lo(GMUPT_HI(q5), ray.ozi), ray.ozi);
     h0 = slab_hit_pk(nxa.x, nya.x, nza.x, fxa.x, fya.x, fza.x); h1 = slab_hit_pk(nxa.y, nya.y, nza.y, fxa.y, fya.y, fza.y);
     h2 = slab_hit_pk(nxb.x, nyb.x, nzb.x, fxb.x, fyb.x, fzb.x); h3 = slab_hit_pk(nxb.y, nyb.y, nzb.y, fxb.y, fyb.y, fzb.y);
 #else
@@ -138,6 +154,45 @@ __device__ __forceinline__ void slab_hits4(const vec4f q0, const vec4f q1, const
     h2 = slab_hit(q0.z, q1.z, q2.z, q3.z, q4.z, q5.z, o, invdir); h3 = slab_hit(q0.w, q1.w, q2.w, q3.w, q4.w, q5.w, o, invdir);
 #endif
 }
+
+// Moeller-Trumbore (extensionRayCast.hlsl:38-62 == shadowRayCast.hlsl:16-40) on the TWO triangles of a TriPair at once: every operation of
+// tri_compute_flat, in its order, on a (first, second) pair of operands -- packed where the machine has the instruction (sub, mul, add),
+// the scalar instruction twice where it has not (the correctly rounded division, the comparisons).  okA / okB: not rejected.
+struct PairHit { vec2f t, u, v; bool okA, okB; bool last; };
+__device__ __forceinline__ PairHit tri_pair_compute(const vec4f a0, const vec4f a1, const vec4f a2, const vec4f a3, const vec4f a4, const RayPk& ray)
+{
+    const vec2f v0x = GMUPT_LO(a0), v0y = GMUPT_HI(a0), v0z = GMUPT_LO(a1), e1x = GMUPT_HI(a1), e1y = GMUPT_LO(a2), e1z = GMUPT_HI(a2);
+    const vec2f e2x = GMUPT_LO(a3), e2y = GMUPT_HI(a3), e2z = GMUPT_LO(a4);
+    PairHit h;
+#if GMUPT_WIDE_PK
+    // pvec = cross3(d, e2) = (d.y e2.z - d.z e2.y, d.z e2.x - d.x e2.z, d.x e2.y - d.y e2.x)
+    const vec2f px = pk_sub(pk_mul_hi(e2z, ray.dxy), pk_mul_lo(e2y, ray.dzz)), py = pk_sub(pk_mul_lo(e2x, ray.dzz), pk_mul_lo(e2z, ray.dxy)), pz = pk_sub(pk_mul_lo(e2y, ray.dxy), pk_mul_hi(e2x, ray.dxy));
+    const vec2f det = pk_add(pk_add(pk_mul(e1x, px), pk_mul(e1y, py)), pk_mul(e1z, pz));                     // dot3(e1, pvec)
+    vec2f invDet; invDet.x = 1.0f / det.x; invDet.y = 1.0f / det.y;
+    const vec2f tx = pk_lo_sub(v0x, ray.oxy), ty = pk_hi_sub(v0y, ray.oxy), tz = pk_lo_sub(v0z, ray.ozi);   // tvec = o - v0
+    h.u = pk_mul(pk_add(pk_add(pk_mul(tx, px), pk_mul(ty, py)), pk_mul(tz, pz)), invDet);                     // dot3(tvec, pvec) * invDet
+    const vec2f qx = pk_sub(pk_mul(ty, e1z), pk_mul(tz, e1y)), qy = pk_sub(pk_mul(tz, e1x), pk_mul(tx, e1z)), qz = pk_sub(pk_mul(tx, e1y), pk_mul(ty, e1x));   // qvec = cross3(tvec, e1)
+    h.v = pk_mul(pk_add(pk_add(pk_mul_lo(qx, ray.dxy), pk_mul_hi(qy, ray.dxy)), pk_mul_lo(qz, ray.dzz)), invDet);   // dot3(d, qvec) * invDet
+    h.t = pk_mul(pk_add(pk_add(pk_mul(e2x, qx), pk_mul(e2y, qy)), pk_mul(e2z, qz)), invDet);                  // dot3(e2, qvec) * invDet
+#else
+    const f3 o = ray_o(ray), d = ray_d(ray);
+    const vec2f dx = { d.x, d.x }, dy = { d.y, d.y }, dz = { d.z, d.z }, ox = { o.x, o.x }, oy = { o.y, o.y }, oz = { o.z, o.z };
+    const vec2f px = dy * e2z - dz * e2y, py = dz * e2x - dx * e2z, pz = dx * e2y - dy * e2x;
+    const vec2f det = (e1x * px + e1y * py) + e1z * pz;
+    vec2f invDet; invDet.x = 1.0f / det.x; invDet.y = 1.0f / det.y;
+    const vec2f tx = ox - v0x, ty = oy - v0y, tz = oz - v0z;
+    h.u = ((tx * px + ty * py) + tz * pz) * invDet;
+    const vec2f qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;
+    h.v = ((dx * qx + dy * qy) + dz * qz) * invDet;
+    h.t = ((e2x * qx + e2y * qy) + e2z * qz) * invDet;
+#endif
+    h.okA = !((det.x > -kEpsilon && det.x < kEpsilon) | (h.u.x < 0.0f) | (h.u.x > 1.0f) | (h.v.x < 0.0f) | (h.u.x + h.v.x > 1.0f));
+    h.okB = !((det.y > -kEpsilon && det.y < kEpsilon) | (h.u.y < 0.0f) | (h.u.y > 1.0f) | (h.v.y < 0.0f) | (h.u.y + h.v.y > 1.0f));
+    h.last = __builtin_bit_cast(vec4u, a4).z != 0u;   // (whole-vector bit cast: __builtin_bit_cast of a vector ELEMENT reads element 0 with this compiler)
+    return h;
+}
+#undef GMUPT_LO
+#undef GMUPT_HI
 
 template <bool STATS>
 __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
@@ -159,7 +214,8 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
     const uint32_t* qExt = p.queues + (size_t)Q_EXT_RAY * p.P;
     const uint32_t* qSh = p.queues + (size_t)Q_SHADOW_RAY * p.P;
     const __amdgpu_buffer_rsrc_t rNodes = make_rsrc(ts.wnodes, ts.wideCount * 128u);
-    const __amdgpu_buffer_rsrc_t rTris = make_rsrc(ts.tris, (p.scene.numTris + 1u) * 48u);    // + the sentinel record
+    const __amdgpu_buffer_rsrc_t rTris = make_rsrc(ts.tris, (p.scene.numTris + 1u) * 48u);    // + the sentinel record (the exact walk; the source-triangle numbers)
+    const __amdgpu_buffer_rsrc_t rPairs = make_rsrc(ts.pairs, ts.numPairs * 80u);
     const uint32_t topCount = ts.wideTopCount;
     uint32_t next = 0, end = 0, lastBase = 0;
     uint32_t chunkBase = 0, qe0 = kQueueHole, qe1 = kQueueHole;  // the current chunk of queue entries, lane l holds entries l and 64 + l
@@ -169,8 +225,7 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
     bool haveRay = false;
     int kind = 0;                 // 0: extension ray, 1: shadow ray; 2 / 3: the same, PARKED for the exact walk
     uint32_t index = 0;
-    RayPk ray; ray_set(ray, mk3(0, 0, 0), mk3(1, 1, 1));   // origin and 1 / d of the lane's ray
-    f3 d = mk3(0, 0, 1);
+    RayPk ray; ray_set(ray, mk3(0, 0, 0), mk3(1, 1, 1));   // origin, direction and 1 / d of the lane's ray
     float distance = kFltMax;     // extension: closest hit so far; shadow: distance of the light
     float hu = 0.0f, hv = 0.0f;
     int hitRef = -1;              // extension: triangle record of the closest hit; shadow: >= 0 when occluded
@@ -195,7 +250,7 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
          tT = kFltMax; refT = -1; redoT = false; } while (0)
     // the end of a decided ray in its lane
 #define GMUPT_WIDE_FINISH() \
-    do { if (kind == 0) finish_extension_ray(p, index, ray_o(ray), d, distance, hu, hv, hitRef);   /* extensionRayCast.hlsl:218-232 */ \
+    do { if (kind == 0) finish_extension_ray(p, index, ray_o(ray), ray_d(ray), distance, hu, hv, hitRef >= 0 ? (int)ts.pairRef[hitRef] : -1);   /* extensionRayCast.hlsl:218-232; hitRef is a pair SLOT */ \
          else stu(p, F_IN_SHADOW, index, hitRef >= 0 ? 1u : 0u);                                    /* shadowRayCast.hlsl:167 */ \
          haveRay = false; redo = false; } while (0)
 
@@ -258,11 +313,11 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
                 const int src = __shfl(donorOfRank, takes ? (int)fRank : 0);
                 const int srcLane = takes ? src : (int)lane;
                 const int node2 = __shfl(node, srcLane), k2 = __shfl(kind, srcLane), i2 = __shfl((int)index, srcLane);
-                const float ox = __shfl(ray.oxy.x, srcLane), oy = __shfl(ray.oxy.y, srcLane), oz = __shfl(ray.ozi.x, srcLane), dx = __shfl(d.x, srcLane), dy = __shfl(d.y, srcLane), dz = __shfl(d.z, srcLane);
+                const float ox = __shfl(ray.oxy.x, srcLane), oy = __shfl(ray.oxy.y, srcLane), oz = __shfl(ray.ozi.x, srcLane), dx = __shfl(ray.dxy.x, srcLane), dy = __shfl(ray.dxy.y, srcLane), dz = __shfl(ray.dzz.x, srcLane);
                 const float lim = __shfl(distance, srcLane);
                 if (takes) {
                     haveRay = true; owner = src; kind = k2; index = (uint32_t)i2; donations = 0;
-                    d = mk3(dx, dy, dz); ray_set(ray, mk3(ox, oy, oz), d);
+                    ray_set(ray, mk3(ox, oy, oz), mk3(dx, dy, dz));
                     distance = k2 == 1 ? lim : kFltMax;     // shadow: the distance of the light; extension: no hit yet
                     hitRef = -1; hu = 0.0f; hv = 0.0f; redo = false;
                     pa = 0; bottom = 0; pb = S - 1; outstanding = 0; ti = -1;
@@ -286,10 +341,9 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
                 if (lane == 0u) atomicAdd(&p.stats->castRedoRays, (unsigned long long)nParked);
                 if (parked) {
                     const bool shadowRay = kind == 3;
-                    d = shadowRay ? ld3(p, F_SH_DX, index) : ld3(p, F_RAY_DX, index);
-                    ray_set(ray, shadowRay ? ld3(p, F_SH_OX, index) : ld3(p, F_RAY_OX, index), d);
+                    ray_set(ray, shadowRay ? ld3(p, F_SH_OX, index) : ld3(p, F_RAY_OX, index), shadowRay ? ld3(p, F_SH_DX, index) : ld3(p, F_RAY_DX, index));
                     distance = shadowRay ? ldf(p, F_LIGHT_DIST, index) : kFltMax;
-                    const f3 o = ray_o(ray), invdir = ray_inv(ray);
+                    const f3 o = ray_o(ray), invdir = ray_inv(ray), d = ray_d(ray);
                     hitRef = -1; hu = 0.0f; hv = 0.0f;
                     int* ovf = p.ovfStack + gtid;
                     uint32_t sp = 0;
@@ -371,8 +425,8 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
                     bottom = 0; donations = 0;
                     haveRay = true; kind = phase; index = newIndex;            // phase is 0 (extension) or 1 (shadow) here
                     if (STATS) { if (phase == 0) raysE++; else raysS++; }
-                    d = newD; distance = newDist;
-                    ray_set(ray, newO, d);
+                    distance = newDist;
+                    ray_set(ray, newO, newD);
                     hitRef = -1; hu = 0.0f; hv = 0.0f; redo = false;
                     pa = 0; pb = S - 1; ti = -1;
                     cur = (ray_box(ts.rootMin[0], ts.rootMin[1], ts.rootMin[2], ts.rootMax[0], ts.rootMax[1], ts.rootMax[2], newO, ray_inv(ray)) > 0.0f) ? 0 : kDone;   // WNode 0 is the root's
@@ -398,46 +452,71 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
         }
 #pragma unroll
         for (int rep = 0; rep < REPS; rep++) {
-            // fetch phase
-            const bool doNode = cur >= 0 && pb >= pa && pb - pa >= (uint32_t)(kWideRoom - 1);
-            vec4f q0, q1, q2, q3, q4, q5; vec4i lk;           // defined for the doNode lanes only
-            if (doNode) load_wnode(rNodes, s_top, topCount, cur, q0, q1, q2, q3, q4, q5, lk);
-            if (burst && ti < 0 && pb != (uint32_t)(S - 1)) { pb++; ti = ~sl[pb * kDefBlock]; }
-            const bool doTri = burst && ti >= 0;
-            vec4f r0, r1; vec2f r2;                          // defined for the doTri lanes only
-            if (doTri) tri_fetch_buf(rTris, ti, r0, r1, r2);
-            // compute phase
-            if (doNode) {
-                if (STATS) { if (kind == 0) tcE.inner++; else tcS.inner++; if (prefix_rank(__ballot(1)) == 0) { if (phase == 0) wInE++; else wInS++; }
-                             if ((uint32_t)cur < topCount) { if (kind == 0) topE++; else topS++; }
-                             boxes += (uint32_t)ts.wnodes[cur].aux[1]; }
-                bool h0, h1, h2, h3;
-                slab_hits4(q0, q1, q2, q3, q4, q5, ray, h0, h1, h2, h3);
-                int nxt = kDone;
+#ifndef GMUPT_WIDE_TOPSTEPS
+#define GMUPT_WIDE_TOPSTEPS 0   // (measured: 1 -> +6 %, 2 -> +18 % of the launch time: the kernel is bound by instruction issue, not by the round trip)
+#endif
+            // the four slab tests of the node in q0 .. lk, then: one hit inner slot is the next node, the other hits are pushed (inner / leaves)
+#define GMUPT_WIDE_NODE_COMPUTE(INTOP) \
+            { if (STATS) { if (kind == 0) tcE.inner++; else tcS.inner++; if (prefix_rank(__ballot(1)) == 0) { if (phase == 0) wInE++; else wInS++; } \
+                           if (INTOP) { if (kind == 0) topE++; else topS++; } boxes += (uint32_t)ts.wnodes[cur].aux[1]; } \
+              bool h0, h1, h2, h3; \
+              slab_hits4(q0, q1, q2, q3, q4, q5, ray, h0, h1, h2, h3); \
+              int nxt = kDone; \
+              GMUPT_WIDE_SLOT(h0, lk.x) GMUPT_WIDE_SLOT(h1, lk.y) GMUPT_WIDE_SLOT(h2, lk.z) GMUPT_WIDE_SLOT(h3, lk.w) \
+              if (nxt < 0) { if (pa > bottom) { pa--; nxt = sl[pa * kDefBlock]; } else { pa = 0; bottom = 0; } }   /* (an empty inner stack frees its dead entries) */ \
+              cur = nxt; }
 #define GMUPT_WIDE_SLOT(H, L) \
                 if (H) { const int l = (L); \
                     if (l >= 0) { if (nxt < 0) nxt = l; else { sl[pa * kDefBlock] = l; pa++; } } \
                     else { sl[pb * kDefBlock] = l; pb--; if (STATS) { if (kind == 0) tcE.leaves++; else tcS.leaves++; } } }
-                GMUPT_WIDE_SLOT(h0, lk.x) GMUPT_WIDE_SLOT(h1, lk.y) GMUPT_WIDE_SLOT(h2, lk.z) GMUPT_WIDE_SLOT(h3, lk.w)
-#undef GMUPT_WIDE_SLOT
-                if (nxt < 0) {
-                    if (pa > bottom) { pa--; nxt = sl[pa * kDefBlock]; }
-                    else { pa = 0; bottom = 0; }   // the inner stack is empty: its dead entries (given to helpers) are free again
+            vec4f q0, q1, q2, q3, q4, q5; vec4i lk;
+            // extra steps for the lanes whose node lives in LDS: they do not have to wait for the vector-memory round trip of the step below,
+            // so a ray gets through the top of the tree at LDS speed (the order of the visits is free)
+#pragma unroll
+            for (int ts_ = 0; ts_ < GMUPT_WIDE_TOPSTEPS; ts_++) {
+                if (cur >= 0 && (uint32_t)cur < topCount && pb >= pa && pb - pa >= (uint32_t)(kWideRoom - 1)) {
+                    load_wnode_lds(s_top, cur, q0, q1, q2, q3, q4, q5, lk);
+                    GMUPT_WIDE_NODE_COMPUTE(true)
                 }
-                cur = nxt;
             }
+            // fetch phase
+            const bool doNode = cur >= 0 && pb >= pa && pb - pa >= (uint32_t)(kWideRoom - 1);
+            const bool inTop = (uint32_t)cur < topCount;
+            if (doNode && inTop) load_wnode_lds(s_top, cur, q0, q1, q2, q3, q4, q5, lk);
+            asm volatile("" ::: "memory");   // LDS lanes first, see load_node
+            if (doNode && !inTop) load_wnode_glb(rNodes, cur, q0, q1, q2, q3, q4, q5, lk);
+            if (burst && ti < 0 && pb != (uint32_t)(S - 1)) { pb++; ti = ~sl[pb * kDefBlock]; }
+            const bool doTri = burst && ti >= 0;
+            vec4f a0, a1, a2, a3, a4;                        // defined for the doTri lanes only: the TriPair of this step
             if (doTri) {
-                if (STATS) { if (kind == 0) tcE.tris++; else tcS.tris++; if (prefix_rank(__ballot(1)) == 0) { if (phase == 0) wTrE++; else wTrS++; } }
-                float t = 0.0f, u = 0.0f, v = 0.0f; bool last;
-                if (tri_compute_flat(make_float4(r0.x, r0.y, r0.z, r0.w), make_float4(r1.x, r1.y, r1.z, r1.w),
-                                     make_float4(r2.x, r2.y, 0.0f, 0.0f), ray_o(ray), d, t, u, v, last)) {
-                    if (kind == 0) {
-                        if (t >= 0.0f && t < distance) { distance = t; hitRef = ti; hu = u; hv = v; redo = false; } // extensionRayCast.hlsl:64-74 (a closer hit ends a tie; a full stack ends the walk, so no test follows it)
-                        else if (t == distance && hitRef >= 0) { if (tri_canon(rTris, ti) != tri_canon(rTris, hitRef)) redo = true; } // which one the reference keeps depends on its visit order
-                    } else {
-                        // shadowRayCast.hlsl:41-45,89: t in (1e-8, 1e8) and |d t| < lightDistance => occluded: the ray is decided
-                        if (t > kEpsilon && t < 1.0f / kEpsilon && length3(d * t) < distance) { hitRef = ti; last = true; pb = S - 1; cur = kDone; pa = bottom; redo = false; }
-                    }
+                const int off = ti * 80;
+                a0 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(rPairs, off, 0, 0));
+                a1 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(rPairs, off + 16, 0, 0));
+                a2 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(rPairs, off + 32, 0, 0));
+                a3 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(rPairs, off + 48, 0, 0));
+                a4 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(rPairs, off + 64, 0, 0));
+            }
+            // compute phase
+            if (doNode) GMUPT_WIDE_NODE_COMPUTE(inTop)
+            if (doTri) {
+                if (STATS) { if (prefix_rank(__ballot(1)) == 0) { if (phase == 0) wTrE++; else wTrS++; } }
+                const PairHit h = tri_pair_compute(a0, a1, a2, a3, a4, ray);
+                bool last = h.last;
+                if (STATS) { const uint32_t n = __builtin_bit_cast(vec4u, a4).w; if (kind == 0) tcE.tris += n; else tcS.tris += n; }   // references in this pair (1 or 2; 0 in the pair of an empty leaf)
+                if (kind == 0) {
+                    // extensionRayCast.hlsl:64-74 for the first, then for the second triangle (a closer hit ends a tie; equal t against another triangle is one)
+#define GMUPT_WIDE_ACCEPT(OK, T, U, V, SLOT) \
+                    if (OK) { if ((T) >= 0.0f && (T) < distance) { distance = (T); hitRef = (SLOT); hu = (U); hv = (V); redo = false; } \
+                              else if ((T) == distance && hitRef >= 0) { if (tri_canon(rTris, (int)ts.pairRef[SLOT]) != tri_canon(rTris, (int)ts.pairRef[hitRef])) redo = true; } }
+                    GMUPT_WIDE_ACCEPT(h.okA, h.t.x, h.u.x, h.v.x, 2 * ti)
+                    GMUPT_WIDE_ACCEPT(h.okB, h.t.y, h.u.y, h.v.y, 2 * ti + 1)
+#undef GMUPT_WIDE_ACCEPT
+                } else {
+                    // shadowRayCast.hlsl:41-45,89: t in (1e-8, 1e8) and |d t| < lightDistance => occluded: the ray is decided
+                    const f3 d = ray_d(ray);
+                    const bool occA = h.okA && h.t.x > kEpsilon && h.t.x < 1.0f / kEpsilon && length3(d * h.t.x) < distance;
+                    const bool occB = h.okB && h.t.y > kEpsilon && h.t.y < 1.0f / kEpsilon && length3(d * h.t.y) < distance;
+                    if (occA | occB) { hitRef = 2 * ti; last = true; pb = S - 1; cur = kDone; pa = bottom; redo = false; }
                 }
                 ti = last ? -1 : ti + 1;
             }
@@ -445,6 +524,8 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
     }
 #undef GMUPT_WIDE_MERGE_OWN
 #undef GMUPT_WIDE_FINISH
+#undef GMUPT_WIDE_NODE_COMPUTE
+#undef GMUPT_WIDE_SLOT
     if (STATS) { flush_counts(p.stats, tcE, raysE, true); flush_wave_iters(p.stats, wInE, wTrE, true);
                  flush_counts(p.stats, tcS, raysS, false); flush_wave_iters(p.stats, wInS, wTrS, false);
                  flush_sum(&p.stats->extTopInner, topE); flush_sum(&p.stats->shTopInner, topS); flush_sum(&p.stats->castHelperSubtrees, helped);

@@ -103,7 +103,7 @@ out = {"config": "config5", "triangles": int(scene["num_triangles"]), "nodes": i
        "traversal_bytes": {"node64": n_inner * 64, "tri48": (int(scene["tris"].shape[0]) + 1) * 48},
        "ms_per_step": round(dt / args.steps * 1e3, 4), "mpaths_per_s": round(st.paths_completed / dt / 1e6, 3), "msegments_per_s": round(st.segments / dt / 1e6, 1),
        "stage_ms": {k: round(getattr(st, "ms_" + k) / st.timed_iterations, 4) for k in ("logic", "material", "extend", "shadow")},
-       "kernel_flags": {"fused_cast": bool(st.flags & capi.STAT_FUSED_CAST), "k_cast_f": bool(st.flags & capi.STAT_CAST_FETCH),
+       "kernel_flags": {"fused_cast": bool(st.flags & capi.STAT_FUSED_CAST), "k_cast_f": bool(st.flags & capi.STAT_CAST_FETCH), "k_cast_w": bool(st.flags & capi.STAT_CAST_WIDE),
                         "stack_spill_instantiation": bool(st.flags & capi.STAT_STACK_SPILL), "stack_overflow": bool(st.flags & capi.STAT_STACK_OVERFLOW)}}
 cast_ms = st.ms_extend / st.timed_iterations
 r.close()
@@ -113,22 +113,27 @@ if args.count:
     step(r2, cam2, args.steps); s2 = r2.stats(); r2.close()
     k = float(args.steps)
     top = s2.ext_top_inner + s2.sh_top_inner
-    node_recs = (s2.ext_inner + s2.sh_inner - top) / k          # 64-byte node records fetched from global memory per launch
+    wide = bool(s2.flags & capi.STAT_CAST_WIDE)
+    node_bytes = 112 if wide else 64                            # a WNode is a 128-byte line of which 112 bytes are fetched; a Node64 is 64
+    node_recs = (s2.ext_inner + s2.sh_inner - top) / k          # node records fetched from global memory per launch
     tri_recs = (s2.ext_tris + s2.sh_tris) / k                  # 48-byte triangle records per launch
     rays = (s2.ext_rays + s2.sh_rays) / k
     # bytes the kernel's own algorithm moves per launch: every global node visit 64 B, every triangle test 48 B (40 B used), ray in / hit out per ray
     ray_io = (s2.ext_rays * (4 + 24 + 48) + s2.sh_rays * (4 + 28 + 4)) / k
-    alg_bytes = node_recs * 64 + tri_recs * 48 + ray_io
+    alg_bytes = node_recs * node_bytes + tri_recs * 48 + ray_io
     # what the REFERENCE's kernels would read for the same walks (144 B per inner step, 52 B per triangle test)
     ref_bytes = (s2.ext_rays * (4 + 24 + 48 + 32 * scene["light_count"] + 48) + 96 * s2.ext_inner + 52 * s2.ext_tris
                  + s2.sh_rays * (4 + 24 + 4 + 48 + 4) + 96 * s2.sh_inner + 52 * s2.sh_tris) / k
-    out["cast"] = {"avg_launch_ms": round(cast_ms, 4), "rays_per_launch": rays, "ext_rays_per_launch": s2.ext_rays / k, "shadow_rays_per_launch": s2.sh_rays / k,
+    if wide:
+        out["traversal_bytes"] = {"wnode128": int(s2.wide_nodes) * 128, "tri48": (int(scene["tris"].shape[0]) + 1) * 48, "wide_nodes_in_lds": int(s2.wide_top_nodes), "wide_stack_bound": int(s2.wide_stack_bound)}
+    out["cast"] = {"kernel": "k_cast_w" if wide else "k_cast_f", "node_record_bytes_fetched": node_bytes, "redo_rays_per_launch": round(s2.cast_redo_rays / k, 2),
+                   "avg_launch_ms": round(cast_ms, 4), "rays_per_launch": rays, "ext_rays_per_launch": s2.ext_rays / k, "shadow_rays_per_launch": s2.sh_rays / k,
                    "inner_per_ext_ray": round(s2.ext_inner / max(s2.ext_rays, 1), 2), "tris_per_ext_ray": round(s2.ext_tris / max(s2.ext_rays, 1), 2),
                    "inner_per_shadow_ray": round(s2.sh_inner / max(s2.sh_rays, 1), 2), "tris_per_shadow_ray": round(s2.sh_tris / max(s2.sh_rays, 1), 2),
                    "lds_top_share_of_node_visits": round(top / max(s2.ext_inner + s2.sh_inner, 1), 4),
                    "global_records_per_launch": node_recs + tri_recs, "grecords_per_s": round((node_recs + tri_recs) / (cast_ms * 1e-3) / 1e9, 2),
                    "kernel_bytes_per_launch": int(alg_bytes), "kernel_bytes_gbs": round(alg_bytes / (cast_ms * 1e-3) / 1e9, 1),
-                   "reference_equivalent_bytes_per_launch": int(ref_bytes)}
+                   "reference_equivalent_bytes_per_launch": None if wide else int(ref_bytes)}   # SURVEY 8(d)'s formula needs the BINARY walk's inner-node count
 line = json.dumps(out)
 print(line, flush=True)
 if args.out:

@@ -31,7 +31,7 @@ def main(fetch_dir, write_dir, out, skip=265):
         f = fetch.get(k, (0.0, 0))[0] * 1024.0
         w = write.get(k, (0.0, 0))[0] * 1024.0
         res["kernels"][k] = {"fetch_bytes_raw": int(f), "fetch_bytes_x2": int(2 * f), "write_bytes": int(w), "dispatches": fetch.get(k, (0, 0))[1]}
-        for short in ("k_extend_d", "k_shadow_d", "k_cast_f", "k_cast_m", "k_cast_d"):
+        for short in ("k_extend_d", "k_shadow_d", "k_cast_f", "k_cast_w", "k_cast_m", "k_cast_d"):
             if short in k:
                 res[short + "_hbm_bytes_per_launch"] = int(2 * f + w)
                 res[short + "_hbm_bytes_per_launch_raw"] = int(f + w)

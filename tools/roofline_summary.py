@@ -10,21 +10,23 @@ d = sys.argv[1].rstrip("/")
 run = json.load(open(d + "/run.json"))
 cast = run.get("cast") or run.get("roofline")
 ms_event = cast["avg_launch_ms"]
+# the kernel that was profiled: the one the plain run names (k_cast_w = the wide ray cast, the default; k_cast_f = the binary fused one)
+KERNEL = cast.get("kernel") or ("k_cast_w" if (run.get("kernel_flags") or {}).get("k_cast_w") else "k_cast_f")
 ms_trace = None
 for row in csv.DictReader(open(d + "/kernel_stats.csv")):
-    if "k_cast_f" in row["Name"]:
+    if KERNEL in row["Name"]:
         ms_trace = float(row["AverageNs"]) / 1e6; calls = int(row["Calls"])
 traffic = json.load(open(d + "/pmc_traffic.json"))
-k = [v for n, v in traffic["kernels"].items() if "k_cast_f" in n][0]
+k = [v for n, v in traffic["kernels"].items() if KERNEL in n][0]
 sizes = {}
 cur = None
 for line in open(d + "/ea_read_sizes.txt"):
     if not line.startswith(" "): cur = line.strip(); continue
-    if cur and cur.startswith("k_cast_f"):
+    if cur and cur.startswith(KERNEL):
         name, val = line.split(); sizes[name] = float(val)
 read_bytes = 32 * sizes["TCC_EA0_RDREQ_32B"] + 64 * sizes["TCC_EA0_RDREQ_64B"] + 128 * sizes["TCC_EA0_RDREQ_128B"]
 write_bytes = k["write_bytes"]
-out = {"kernel": "k_cast_f", "avg_launch_ms_hip_events": ms_event, "avg_launch_ms_rocprof_trace": round(ms_trace, 4), "trace_calls": calls,
+out = {"kernel": KERNEL, "avg_launch_ms_hip_events": ms_event, "avg_launch_ms_rocprof_trace": round(ms_trace, 4), "trace_calls": calls,
        "memory_side": {"read_requests_128B": int(sizes["TCC_EA0_RDREQ_128B"]), "read_bytes": int(read_bytes), "FETCH_SIZE_bytes_raw": k["fetch_bytes_raw"],
                        "write_bytes": write_bytes, "bytes_per_launch": int(read_bytes + write_bytes),
                        "gbs": round((read_bytes + write_bytes) / (ms_trace * 1e-3) / 1e9, 1), "hbm_peak_gbs": 8000.0,
@@ -37,7 +39,7 @@ pmc, cur = {}, None
 try:
     for line in open(d + "/pmc_counters.txt"):
         if not line.startswith(" "): cur = line.strip(); continue
-        if cur and cur.startswith("k_cast_f"):
+        if cur and cur.startswith(KERNEL):
             name, val = line.split(); pmc[name] = float(val)
 except FileNotFoundError:
     pass

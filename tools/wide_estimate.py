@@ -128,3 +128,47 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def top_walk_estimate(spheres=202, subdiv=3, rays=3000, top=512):
+    """Phase split of the wide walk: all visits of the LDS-resident top first (no vector memory), then the rest.  Per ray: top-node visits,
+    entries the top walk leaves behind (global inner nodes, leaves), deepest stack of top nodes."""
+    pkg = gmupt_pkg.load()
+    scene = pkg.scenes.build_scene(pkg.scenes.spheres_mesh(spheres, subdiv, seed=1234))
+    nodes = scene["nodes"]
+    slots_of, wide_of = collapse(nodes, 4)
+    area = lambda i: (lambda d: d[0] * d[1] + d[1] * d[2] + d[2] * d[0])(nodes["max"][i].astype(np.float64) - nodes["min"][i])
+    in_top = set(); frontier = [(area(0), 0)]
+    while frontier and len(in_top) < top:
+        frontier.sort(); a, n = frontier.pop(); in_top.add(n)
+        for c in slots_of[wide_of[n]]:
+            if not nodes["isLeaf"][c]:
+                frontier.append((area(c), c))
+    rng = np.random.default_rng(1)
+    lo, hi = nodes["min"][0], nodes["max"][0]
+    o = rng.uniform(lo + 0.05 * (hi - lo), hi - 0.05 * (hi - lo), (rays, 3)).astype(np.float32)
+    d = rng.normal(size=(rays, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    inv = (np.float32(1.0) / d).astype(np.float32)
+    mn, mx = nodes["min"], nodes["max"]
+    tv, gi, gl, depth, allv = [], [], [], [], []
+    for r in range(rays):
+        stack = [0] if slab(mn[0], mx[0], o[r], inv[r]) else []
+        visits = 0; ginner = 0; gleaf = 0; md = 0
+        while stack:
+            md = max(md, len(stack)); n = stack.pop(); visits += 1
+            s = slots_of[wide_of[n]]
+            hit = slab(mn[s], mx[s], o[r], inv[r])
+            for c, h in zip(s, hit):
+                if not h: continue
+                if nodes["isLeaf"][c]: gleaf += 1
+                elif c in in_top: stack.append(c)
+                else: ginner += 1
+        tv.append(visits); gi.append(ginner); gl.append(gleaf); depth.append(md)
+    tv, gi, gl, depth = map(np.array, (tv, gi, gl, depth))
+    left = gi + gl
+    print("top of %d wide nodes: per ray %.2f top visits; left behind: %.2f global inner + %.2f leaves (max %d, 99.9%% %d); deepest top stack %d"
+          % (top, tv.mean(), gi.mean(), gl.mean(), left.max(), int(np.percentile(left, 99.9)), depth.max()))
+
+
+if __name__ == "__main__" and "--top-walk" in sys.argv:
+    pass
