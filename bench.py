@@ -87,10 +87,10 @@ def _rate(points, table_mb):
     return points[k][1] + t * (points[k + 1][1] - points[k][1])
 
 
-def gather_ceiling(ceilings, node_recs, tri_recs, node_shape, table_mb=None):
+def gather_ceiling(ceilings, node_recs, tri_recs, node_shape, table_mb=None, tri_shape="D"):
     """G records/s of a launch that gathers this mix of node and triangle records at the micro-benchmark's rates: every record an L2 hit
     (table_mb None) or a uniformly random table of table_mb."""
-    a, d = _rate(ceilings[node_shape], table_mb), _rate(ceilings["D"], table_mb)
+    a, d = _rate(ceilings[node_shape], table_mb), _rate(ceilings[tri_shape], table_mb)
     return (node_recs + tri_recs) / (node_recs / a + tri_recs / d)
 
 
@@ -201,17 +201,20 @@ def roofline_object(capi, s2, steps, cast_ms, scene, table_mb, profile_dir):
     inner = s2.ext_inner + (s2.sh_inner if fused else 0)
     top = s2.ext_top_inner + (s2.sh_top_inner if fused else 0)
     tris = s2.ext_tris + (s2.sh_tris if fused else 0)
-    node_recs, tri_recs = (inner - top) / k, tris / k
+    # records fetched from global memory per launch: node records below the LDS-resident top; triangle records -- one 48-byte Tri48 per test
+    # (k_cast_f), one 80-byte TriPair per one or two tests (k_cast_w)
+    node_recs, tri_recs = (inner - top) / k, (s2.wide_pair_fetches if wide else tris) / k
     recs = node_recs + tri_recs
     sec = cast_ms * 1e-3
     achieved = recs / sec / 1e9 if sec > 0 else 0.0
     ceilings = load_gather_ceilings()
     shape = "H" if wide else "A"
-    peak = gather_ceiling(ceilings, node_recs, tri_recs, shape) if ceilings else None
-    uniform = gather_ceiling(ceilings, node_recs, tri_recs, shape, table_mb) if ceilings else None
-    node_bytes = 112 if wide else 64
+    tri_shape = "A" if wide else "D"      # an 80-byte pair record is five 16-byte requests: priced at the rate of four (shape A), i.e. a little too high a ceiling
+    peak = gather_ceiling(ceilings, node_recs, tri_recs, shape, None, tri_shape) if ceilings else None
+    uniform = gather_ceiling(ceilings, node_recs, tri_recs, shape, table_mb, tri_shape) if ceilings else None
+    node_bytes, tri_bytes = (112, 80) if wide else (64, 48)
     ray_io = (s2.ext_rays * (4 + 24 + 48) + (s2.sh_rays * (4 + 28 + 4) if fused else 0)) / k
-    kernel_bytes = node_recs * node_bytes + tri_recs * 48 + ray_io
+    kernel_bytes = node_recs * node_bytes + tri_recs * tri_bytes + ray_io
     ref_bytes = None
     if not wide:
         ref_bytes = (s2.ext_rays * (4 + 24 + 48 + 32 * scene["light_count"] + 48) + 96 * s2.ext_inner + 52 * s2.ext_tris) / k
@@ -219,11 +222,11 @@ def roofline_object(capi, s2, steps, cast_ms, scene, table_mb, profile_dir):
             ref_bytes += (s2.sh_rays * (4 + 24 + 4 + 48 + 4) + 96 * s2.sh_inner + 52 * s2.sh_tris) / k
     kname = "k_cast_w" if wide else "k_cast_f" if (s2.flags & capi.STAT_CAST_FETCH) else ("fused ray cast (variant)" if fused else "k_extend_d")
     profile = profile_figures(profile_dir, kname) if profile_dir else None
-    return {"bound": "gather (random %d-byte node records + 48-byte triangle records; vector-memory request rate)" % (128 if wide else 64), "kernel": kname,
+    return {"bound": "gather (random %s; vector-memory request rate)" % ("128-byte node records + 80-byte triangle-pair records" if wide else "64-byte node records + 48-byte triangle records"), "kernel": kname,
             "achieved": round(achieved, 2), "peak": round(peak, 1) if peak else None, "unit": "Grecords/s", "frac": round(achieved / peak, 4) if peak else None, "traffic": None,
-            "peak_source": "tools/micro/gather64.hip shapes %s (nodes) and D (triangles), L2-resident table, weighted by this launch's record mix: %s/ (measured in round 2 on this pool)" % (shape, MICRO_DIR),
+            "peak_source": "tools/micro/gather64.hip shapes %s (nodes) and %s (triangles), L2-resident table, weighted by this launch's record mix: %s/ (measured in round 2 on this pool)" % (shape, tri_shape, MICRO_DIR),
             "uniform_table": {"table_mb": round(table_mb, 1), "grecords_per_s": round(uniform, 1), "frac": round(achieved / uniform, 4)} if uniform else None,
-            "avg_launch_ms": round(cast_ms, 4), "records_per_launch": int(recs), "node_records_per_launch": int(node_recs), "triangle_records_per_launch": int(tri_recs),
+            "avg_launch_ms": round(cast_ms, 4), "records_per_launch": int(recs), "node_records_per_launch": int(node_recs), "triangle_records_per_launch": int(tri_recs), "triangle_tests_per_launch": int(tris / k),
             "lds_top_share_of_node_visits": round(top / max(inner, 1), 4),
             "rays_per_launch": (s2.ext_rays + (s2.sh_rays if fused else 0)) / k, "shadow_rays_per_launch": s2.sh_rays / k,
             "inner_per_ray": round(s2.ext_inner / max(s2.ext_rays, 1), 2), "tris_per_ray": round(s2.ext_tris / max(s2.ext_rays, 1), 2),
@@ -236,7 +239,7 @@ def roofline_object(capi, s2, steps, cast_ms, scene, table_mb, profile_dir):
             "helper_subtrees_per_launch": round(s2.cast_helper_subtrees / k, 1),
             "hbm": {"kernel_bytes_per_launch": int(kernel_bytes), "kernel_bytes_gbs": round(kernel_bytes / sec / 1e9, 1) if sec > 0 else 0.0,
                     "hbm_peak_gbs": HBM_PEAK_GBS, "kernel_bytes_over_hbm_peak": round(kernel_bytes / sec / 1e9 / HBM_PEAK_GBS, 4) if sec > 0 else 0.0,
-                    "note": "cache hits included: the BVH of this scene is L2 / Infinity-Cache resident; measured memory-side bytes per launch: from_profile"},
+                    "note": ("cache hits included: the traversal records of this scene (%.0f MB) are L2 / Infinity-Cache resident" if table_mb < 200 else "the traversal records of this scene (%.0f MB) exceed the 256 MB Infinity Cache: most of these bytes come from HBM") % table_mb + "; measured memory-side bytes per launch: from_profile"},
             "from_profile": profile,
             "reference_equivalent_bytes_per_launch": int(ref_bytes) if ref_bytes is not None else None}
 
@@ -389,7 +392,7 @@ def main_rank(args):
         n_inner = int((scene["nodes"]["isLeaf"] == 0).sum())
         wide = bool(s2.flags & capi.STAT_CAST_WIDE)
         node_table = s2.wide_nodes * 128 if wide else n_inner * 64
-        table_mb = (node_table + (int(scene["tris"].shape[0]) + 1) * 48) / 1e6      # the traversal copy the kernel walked: WNode or Node64 records + Tri48 records
+        table_mb = (node_table + (s2.wide_pairs * 80 if wide else (int(scene["tris"].shape[0]) + 1) * 48)) / 1e6      # the traversal copy the kernel walked: WNode + TriPair, or Node64 + Tri48 records
         # the committed profile belongs to the default workload only
         default_workload = (args.width, args.height, args.pool, args.spheres, args.subdiv) == (1920, 1080, 1 << 21, 202, 3)
         roofline = roofline_object(capi, s2, args.steps, cast_ms, scene, table_mb, PROFILE_DIR if default_workload else None)
@@ -483,7 +486,7 @@ def config5_leg(capi, scenes, dev, args):
     step(r2, cam2, args.config5_steps); s2 = r2.stats(); r2.close()
     n_inner = int((scene["nodes"]["isLeaf"] == 0).sum())
     wide = bool(s2.flags & capi.STAT_CAST_WIDE)
-    table_mb = ((s2.wide_nodes * 128 if wide else n_inner * 64) + (int(scene["tris"].shape[0]) + 1) * 48) / 1e6
+    table_mb = (s2.wide_nodes * 128 + s2.wide_pairs * 80 if wide else n_inner * 64 + (int(scene["tris"].shape[0]) + 1) * 48) / 1e6
     roof = roofline_object(capi, s2, args.config5_steps, cast_ms, scene, table_mb, PROFILE_DIR5)
     sb.close()
     prof = roof.get("from_profile") or {}

@@ -311,6 +311,7 @@ extern "C" int gmupt_renderer_create(gmupt_device* dev, const gmupt_renderer_des
     { const char* wpc = std::getenv("GMUPT_WAVES_PER_CU"); const uint32_t w = wpc ? (uint32_t)std::atoi(wpc) : 16u; const uint32_t db = deferred_block_threads(); p.travGridBlocks = (uint32_t)dev->prop.multiProcessorCount * ((w * 64 + db - 1) / db); if (p.travGridBlocks * db > p.ovfStride) p.travGridBlocks = p.ovfStride / db; if (p.travGridBlocks == 0) p.travGridBlocks = 1; }
     { const char* ep = std::getenv("GMUPT_EXTEND_PRUNE"); p.extendPrune = ep ? (uint32_t)std::atoi(ep) : 0u; }
     { const char* sp = std::getenv("GMUPT_SHADOW_PRUNE"); p.shadowPrune = sp ? (uint32_t)std::atoi(sp) : 0u; }
+    { const char* xb = std::getenv("GMUPT_XCD_BINS"); p.xcdBins = xb ? (uint32_t)std::atoi(xb) : 0u; }
     { const char* lc = std::getenv("GMUPT_CAST_LOOP_CAP"); p.castLoopCap = lc ? (uint32_t)std::atoi(lc) : (1u << 20); if (p.castLoopCap == 0) p.castLoopCap = 1u << 20; }
     { const char* e1 = std::getenv("GMUPT_REFILL"); p.tuneRefill = e1 ? (uint32_t)std::atoi(e1) : 20u; const char* e2 = std::getenv("GMUPT_TRI_THRESH"); p.tuneTriThresh = e2 ? (uint32_t)std::atoi(e2) : ((r->travMode == 60 || r->travMode == 63 || r->travMode == 70) ? 24u : 32u); } // fused fetches make a burst cheaper
 
@@ -326,7 +327,7 @@ extern "C" int gmupt_renderer_create(gmupt_device* dev, const gmupt_renderer_des
     if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.queues, (size_t)P * 20, 0);
     if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.qc, 32, 0);
     if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.stats, sizeof(DevStats), 0);
-    if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.travCounters, 16, 0);
+    if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.travCounters, 128, 0);
     if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.ovfStack, (size_t)p.ovfStride * traversal_overflow_entries() * 4, 0);
     if (rc == GMUPT_OK) rc = alloc_framebuffer(r, desc->width, desc->height);
     if (rc == GMUPT_OK) {
@@ -741,7 +742,7 @@ static int run_iteration(gmupt_renderer* r, bool doShade, bool doExtend, bool do
         launch_material(p, clearFrame, r->stream);  // computes its own queue offsets (no scan launch)
         if (ev) HIP_TRY(hipEventRecord(ev->e[2], r->stream));
     }
-    if (!doShade) HIP_TRY(hipMemsetAsync(p.travCounters, 0, 16, r->stream)); // k_material (block 0) zeroes the ray-cast work counters in a full iteration
+    if (!doShade) HIP_TRY(hipMemsetAsync(p.travCounters, 0, 128, r->stream)); // k_material (block 0) zeroes the ray-cast work counters in a full iteration
     if (doExtend && doShadow && traversal_is_fused(r->travMode)) {
         // one launch for both ray casts; its time is reported as the extension stage, the shadow stage as zero
         const uint32_t launched = launch_cast(p, stats, r->travMode, r->stream);
@@ -883,7 +884,7 @@ extern "C" int gmupt_get_stats(gmupt_renderer* r, gmupt_stats* out)
     out->cast_waves = ds.castWaves; out->cast_wave_ticks = ds.castWaveClocks; out->cast_wave_ticks_max = ds.castWaveClocksMax;
     out->cast_drain_ticks = ds.castDrainClocks; out->cast_drain_iters = ds.castDrainIters; out->cast_drain_busy_lanes = ds.castDrainBusyLanes;
     out->ext_top_inner = ds.extTopInner; out->sh_top_inner = ds.shTopInner; out->cast_helper_subtrees = ds.castHelperSubtrees;
-    out->cast_nested_helpers = ds.castNestedHelpers; out->cast_redo_rays = ds.castRedoRays; out->wide_nodes = r->p.trav.wideCount; out->wide_top_nodes = r->p.trav.wideTopCount; out->wide_stack_bound = r->p.trav.wideStackBound; out->wide_box_tests = ds.wideBoxTests;
+    out->cast_nested_helpers = ds.castNestedHelpers; out->cast_redo_rays = ds.castRedoRays; out->wide_nodes = r->p.trav.wideCount; out->wide_top_nodes = r->p.trav.wideTopCount; out->wide_stack_bound = r->p.trav.wideStackBound; out->wide_pairs = r->p.trav.numPairs; out->wide_pair_fetches = ds.widePairFetches; out->wide_box_tests = ds.wideBoxTests;
     out->ext_wave_inner = ds.extWaveInner; out->ext_wave_tris = ds.extWaveTris; out->sh_wave_inner = ds.shWaveInner; out->sh_wave_tris = ds.shWaveTris;
     if (ds.stackOverflow & 3u) return fail(GMUPT_ERR_CAST_FAULT, "gmupt_get_stats: a ray-cast launch flagged its results as invalid (flags %#x; the statistics are filled in)", out->flags);
     return GMUPT_OK;

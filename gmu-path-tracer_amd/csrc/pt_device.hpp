@@ -63,6 +63,7 @@ struct DevStats {
     unsigned long long castHelperSubtrees;      // subtrees handed to idle lanes in the drain of the fused ray cast
     unsigned long long castNestedHelpers;       // of those: subtrees a HELPER gave away in turn (collect_stats)
     unsigned long long castRedoRays;            // wide ray cast: rays walked again in the reference's binary order (closest hit an exact tie between two triangles; a full stack)
+    unsigned long long widePairFetches;         // wide ray cast, collect_stats: 80-byte TriPair records fetched (a leaf of n references takes ceil(n / 2))
     unsigned long long wideBoxTests;            // wide ray cast, collect_stats: occupied box slots tested
     uint32_t activePaths;
     uint32_t stackOverflow; // bit 0: traversal needed more than the provisioned stack (results then differ from an unbounded stack); bit 1: a wave of the fused ray cast left at its iteration limit
@@ -168,11 +169,12 @@ struct RenderParams {
     int* ovfStack;         // global overflow of the traversal stacks
     uint32_t ovfStride;    // threads of the traversal grid
     uint32_t raysPerWave;  // queue entries owned by one wave of the persistent ray-cast kernels
-    uint32_t* travCounters; // [0] extension, [1] shadow: next unassigned queue entry (zeroed by k_material every iteration)
+    uint32_t* travCounters; // [0] extension, [1] shadow: next unassigned queue entry (zeroed by k_material every iteration); [4 + 8 phase + segment]: the same per queue segment (XCD experiment)
     uint32_t travGridBlocks; // persistent ray-cast grid
     uint32_t extendPrune;  // 1: the extension ray skips boxes it enters beyond its current closest hit (see pt_traverse.hip)
     uint32_t shadowPrune;  // 1: the shadow ray skips boxes it enters beyond the light (cannot change its boolean result)
     uint32_t tuneRefill, tuneTriThresh; // lane-refill / triangle-burst thresholds of the deferred-leaf kernels
+    uint32_t xcdBins;      // experiment builds only (-DGMUPT_WIDE_XCD_EXPERIMENT): the queues are eight equal segments, a wave serves the segment of its XCD first
     uint32_t castLoopCap;  // watchdog of the fused ray cast: loop iterations after which a wave gives up (GMUPT_STAT_CAST_ABORTED)
     gmupt_camera_buffer cam;
     SceneView scene;

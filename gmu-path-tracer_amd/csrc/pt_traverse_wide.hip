@@ -220,7 +220,7 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
     uint32_t next = 0, end = 0, lastBase = 0;
     uint32_t chunkBase = 0, qe0 = kQueueHole, qe1 = kQueueHole;  // the current chunk of queue entries, lane l holds entries l and 64 + l
     int phase = 0;
-    uint32_t census0 = 0, census1 = 0, census2 = 0, census3 = 0, topE = 0, topS = 0, helped = 0, nested = 0, boxes = 0;
+    uint32_t census0 = 0, census1 = 0, census2 = 0, census3 = 0, topE = 0, topS = 0, helped = 0, nested = 0, boxes = 0, pairFetches = 0;
 
     bool haveRay = false;
     int kind = 0;                 // 0: extension ray, 1: shadow ray; 2 / 3: the same, PARKED for the exact walk
@@ -389,6 +389,31 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
             }
         }
         if (nIdle == 64 || (nIdle >= (int)p.tuneRefill && phase < 2)) { // wave-uniform
+#ifndef GMUPT_WIDE_XCD_EXPERIMENT
+#define GMUPT_WIDE_XCD_EXPERIMENT 0   // 1 (tools/xcd_experiment.py only): queues pre-binned into eight equal segments, one per XCD (does an L2 per subtree pay?)
+#endif
+#if GMUPT_WIDE_XCD_EXPERIMENT
+            while (p.xcdBins && next >= end && phase < 2) {
+                const uint32_t count = phase == 0 ? countExt : countSh, segLen = count >> 3;
+                const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;     // HW_REG_XCC_ID: the XCD this workgroup runs on
+                bool got = false;
+                for (uint32_t t = 0; t < 8u && !got; t++) {
+                    const uint32_t sgm = (xcc + t) & 7u;
+                    uint32_t base = 0;
+                    if (lane == 0u) base = atomicAdd(&p.travCounters[4u + 8u * (uint32_t)phase + sgm], p.raysPerWave);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    if (base < segLen) {
+                        got = true;
+                        const uint32_t gb = sgm * segLen + base, ge = (base + p.raysPerWave < segLen ? gb + p.raysPerWave : (sgm + 1u) * segLen);
+                        next = gb; end = ge; chunkBase = gb;
+                        const uint32_t* q = phase == 0 ? qExt : qSh;
+                        qe0 = (gb + lane < ge) ? q[gb + lane] : kQueueHole;
+                        qe1 = (gb + 64u + lane < ge) ? q[gb + 64u + lane] : kQueueHole;
+                    }
+                }
+                if (!got) { phase++; next = end = 0; }
+            }
+#endif
             while (next >= end && phase < 2) { // next chunk of the current queue, or the first one of the next queue
                 uint32_t base = 0;
                 const uint32_t count = phase == 0 ? countExt : countSh;
@@ -414,7 +439,7 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
                 // the next ray first: its loads are in flight while the finished ray is written back
                 const bool take = my < end;
                 const uint32_t newIndex = take ? (entry < 64u ? entryLo : entryHi) : kQueueHole;   // extensionRayCast.hlsl:210 / shadowRayCast.hlsl:159
-                const bool newRay = take && (phase != 0 || newIndex != kQueueHole); // holes only exist in the extension queue
+                const bool newRay = take && ((phase != 0 && !GMUPT_WIDE_XCD_EXPERIMENT) || newIndex != kQueueHole); // holes only exist in the extension queue (and in the experiment's padded bins)
                 f3 newO = mk3(0, 0, 0), newD = mk3(0, 0, 1); float newDist = kFltMax;
                 if (newRay) {
                     if (phase == 0) { newO = ld3(p, F_RAY_OX, newIndex); newD = ld3(p, F_RAY_DX, newIndex); }                 // :213-214
@@ -499,7 +524,7 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
             // compute phase
             if (doNode) GMUPT_WIDE_NODE_COMPUTE(inTop)
             if (doTri) {
-                if (STATS) { if (prefix_rank(__ballot(1)) == 0) { if (phase == 0) wTrE++; else wTrS++; } }
+                if (STATS) { pairFetches++; if (prefix_rank(__ballot(1)) == 0) { if (phase == 0) wTrE++; else wTrS++; } }
                 const PairHit h = tri_pair_compute(a0, a1, a2, a3, a4, ray);
                 bool last = h.last;
                 if (STATS) { const uint32_t n = __builtin_bit_cast(vec4u, a4).w; if (kind == 0) tcE.tris += n; else tcS.tris += n; }   // references in this pair (1 or 2; 0 in the pair of an empty leaf)
@@ -529,7 +554,7 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
     if (STATS) { flush_counts(p.stats, tcE, raysE, true); flush_wave_iters(p.stats, wInE, wTrE, true);
                  flush_counts(p.stats, tcS, raysS, false); flush_wave_iters(p.stats, wInS, wTrS, false);
                  flush_sum(&p.stats->extTopInner, topE); flush_sum(&p.stats->shTopInner, topS); flush_sum(&p.stats->castHelperSubtrees, helped);
-                 flush_sum(&p.stats->castNestedHelpers, nested); flush_sum(&p.stats->wideBoxTests, boxes);
+                 flush_sum(&p.stats->castNestedHelpers, nested); flush_sum(&p.stats->wideBoxTests, boxes); flush_sum(&p.stats->widePairFetches, pairFetches);
                  if (lane == 0u) {
                      atomicAdd(&p.stats->castWaves, 1ull);
                      atomicAdd(&p.stats->laneCensus[0], (unsigned long long)census0); atomicAdd(&p.stats->laneCensus[1], (unsigned long long)census1);

@@ -195,6 +195,7 @@ typedef struct {
                                              two triangles, or a traversal stack ran full) */
     uint64_t wide_nodes, wide_top_nodes, wide_stack_bound; /* the 4-wide collapse of the bound scene (GMUPT_TRAVERSAL=wide; 0 when none was built): 128-byte records,
                                              how many of them live in LDS, and the most entries the inner stack of a walk could hold (every slot hit on every level) */
+    uint64_t wide_pairs, wide_pair_fetches; /* the leaves of that collapse as 80-byte triangle-pair records: how many there are; how many were fetched (collect_stats) */
     uint64_t wide_box_tests;              /* wide ray cast, collect_stats: occupied box slots tested */
 } gmupt_stats;
 int gmupt_get_stats(gmupt_renderer* r, gmupt_stats* out); /* synchronises */

@@ -116,16 +116,17 @@ if args.count:
     wide = bool(s2.flags & capi.STAT_CAST_WIDE)
     node_bytes = 112 if wide else 64                            # a WNode is a 128-byte line of which 112 bytes are fetched; a Node64 is 64
     node_recs = (s2.ext_inner + s2.sh_inner - top) / k          # node records fetched from global memory per launch
-    tri_recs = (s2.ext_tris + s2.sh_tris) / k                  # 48-byte triangle records per launch
+    tri_recs = (s2.wide_pair_fetches if wide else s2.ext_tris + s2.sh_tris) / k   # triangle records per launch: 48-byte Tri48 (one test), or 80-byte TriPair (one or two tests)
+    tri_bytes = 80 if wide else 48
     rays = (s2.ext_rays + s2.sh_rays) / k
     # bytes the kernel's own algorithm moves per launch: every global node visit 64 B, every triangle test 48 B (40 B used), ray in / hit out per ray
     ray_io = (s2.ext_rays * (4 + 24 + 48) + s2.sh_rays * (4 + 28 + 4)) / k
-    alg_bytes = node_recs * node_bytes + tri_recs * 48 + ray_io
+    alg_bytes = node_recs * node_bytes + tri_recs * tri_bytes + ray_io
     # what the REFERENCE's kernels would read for the same walks (144 B per inner step, 52 B per triangle test)
     ref_bytes = (s2.ext_rays * (4 + 24 + 48 + 32 * scene["light_count"] + 48) + 96 * s2.ext_inner + 52 * s2.ext_tris
                  + s2.sh_rays * (4 + 24 + 4 + 48 + 4) + 96 * s2.sh_inner + 52 * s2.sh_tris) / k
     if wide:
-        out["traversal_bytes"] = {"wnode128": int(s2.wide_nodes) * 128, "tri48": (int(scene["tris"].shape[0]) + 1) * 48, "wide_nodes_in_lds": int(s2.wide_top_nodes), "wide_stack_bound": int(s2.wide_stack_bound)}
+        out["traversal_bytes"] = {"wnode128": int(s2.wide_nodes) * 128, "tripair80": int(s2.wide_pairs) * 80, "wide_nodes_in_lds": int(s2.wide_top_nodes), "wide_stack_bound": int(s2.wide_stack_bound)}
     out["cast"] = {"kernel": "k_cast_w" if wide else "k_cast_f", "node_record_bytes_fetched": node_bytes, "redo_rays_per_launch": round(s2.cast_redo_rays / k, 2),
                    "avg_launch_ms": round(cast_ms, 4), "rays_per_launch": rays, "ext_rays_per_launch": s2.ext_rays / k, "shadow_rays_per_launch": s2.sh_rays / k,
                    "inner_per_ext_ray": round(s2.ext_inner / max(s2.ext_rays, 1), 2), "tris_per_ext_ray": round(s2.ext_tris / max(s2.ext_rays, 1), 2),
