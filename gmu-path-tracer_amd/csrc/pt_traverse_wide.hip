@@ -480,20 +480,29 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
 #ifndef GMUPT_WIDE_TOPSTEPS
 #define GMUPT_WIDE_TOPSTEPS 0   // (measured: 1 -> +6 %, 2 -> +18 % of the launch time: the kernel is bound by instruction issue, not by the round trip)
 #endif
-            // the four slab tests of the node in q0 .. lk, then: one hit inner slot is the next node, the other hits are pushed (inner / leaves)
+            // the four slab tests of the node in q0 .. lk, then: the first hit inner slot is the next node, the other hits are pushed (inner nodes from the
+            // bottom, leaves from the top) -- ranks by prefix counts, one predicated LDS store per slot and stack (nested regions per slot: the same time)
 #define GMUPT_WIDE_NODE_COMPUTE(INTOP) \
             { if (STATS) { if (kind == 0) tcE.inner++; else tcS.inner++; if (prefix_rank(__ballot(1)) == 0) { if (phase == 0) wInE++; else wInS++; } \
                            if (INTOP) { if (kind == 0) topE++; else topS++; } boxes += (uint32_t)ts.wnodes[cur].aux[1]; } \
               bool h0, h1, h2, h3; \
               slab_hits4(q0, q1, q2, q3, q4, q5, ray, h0, h1, h2, h3); \
-              int nxt = kDone; \
-              GMUPT_WIDE_SLOT(h0, lk.x) GMUPT_WIDE_SLOT(h1, lk.y) GMUPT_WIDE_SLOT(h2, lk.z) GMUPT_WIDE_SLOT(h3, lk.w) \
+              const bool i0 = h0 & (lk.x >= 0), i1 = h1 & (lk.y >= 0), i2 = h2 & (lk.z >= 0), i3 = h3 & (lk.w >= 0); \
+              const bool f0 = h0 & (lk.x < 0), f1 = h1 & (lk.y < 0), f2 = h2 & (lk.z < 0), f3_ = h3 & (lk.w < 0); \
+              const uint32_t r1 = i0 ? 1u : 0u, r2 = r1 + (i1 ? 1u : 0u), r3 = r2 + (i2 ? 1u : 0u), cI = r3 + (i3 ? 1u : 0u);   /* inner hits before slot k */ \
+              const uint32_t s1 = f0 ? 1u : 0u, s2 = s1 + (f1 ? 1u : 0u), s3 = s2 + (f2 ? 1u : 0u), cL = s3 + (f3_ ? 1u : 0u);  /* leaf hits before slot k */ \
+              int nxt = i0 ? lk.x : (i1 ? lk.y : (i2 ? lk.z : (i3 ? lk.w : kDone)));                                            /* the first hit inner slot is the next node */ \
+              if (i1 & (r1 != 0u)) sl[(pa + r1 - 1u) * kDefBlock] = lk.y; \
+              if (i2 & (r2 != 0u)) sl[(pa + r2 - 1u) * kDefBlock] = lk.z; \
+              if (i3 & (r3 != 0u)) sl[(pa + r3 - 1u) * kDefBlock] = lk.w; \
+              if (f0) sl[pb * kDefBlock] = lk.x; \
+              if (f1) sl[(pb - s1) * kDefBlock] = lk.y; \
+              if (f2) sl[(pb - s2) * kDefBlock] = lk.z; \
+              if (f3_) sl[(pb - s3) * kDefBlock] = lk.w; \
+              pa += cI != 0u ? cI - 1u : 0u; pb -= cL; \
+              if (STATS) { if (kind == 0) tcE.leaves += cL; else tcS.leaves += cL; } \
               if (nxt < 0) { if (pa > bottom) { pa--; nxt = sl[pa * kDefBlock]; } else { pa = 0; bottom = 0; } }   /* (an empty inner stack frees its dead entries) */ \
               cur = nxt; }
-#define GMUPT_WIDE_SLOT(H, L) \
-                if (H) { const int l = (L); \
-                    if (l >= 0) { if (nxt < 0) nxt = l; else { sl[pa * kDefBlock] = l; pa++; } } \
-                    else { sl[pb * kDefBlock] = l; pb--; if (STATS) { if (kind == 0) tcE.leaves++; else tcS.leaves++; } } }
             vec4f q0, q1, q2, q3, q4, q5; vec4i lk;
             // extra steps for the lanes whose node lives in LDS: they do not have to wait for the vector-memory round trip of the step below,
             // so a ray gets through the top of the tree at LDS speed (the order of the visits is free)
@@ -550,7 +559,6 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
 #undef GMUPT_WIDE_MERGE_OWN
 #undef GMUPT_WIDE_FINISH
 #undef GMUPT_WIDE_NODE_COMPUTE
-#undef GMUPT_WIDE_SLOT
     if (STATS) { flush_counts(p.stats, tcE, raysE, true); flush_wave_iters(p.stats, wInE, wTrE, true);
                  flush_counts(p.stats, tcS, raysS, false); flush_wave_iters(p.stats, wInS, wTrS, false);
                  flush_sum(&p.stats->extTopInner, topE); flush_sum(&p.stats->shTopInner, topS); flush_sum(&p.stats->castHelperSubtrees, helped);

@@ -146,3 +146,30 @@ def test_wide_with_tiny_stacks_parks_rays_for_the_exact_walk(pkg, monkeypatch, s
         assert sh.flags & pkg.capi.STAT_CAST_WIDE and not (sh.flags & (pkg.capi.STAT_STACK_OVERFLOW | pkg.capi.STAT_CAST_ABORTED))
         assert sh.cast_redo_rays > 500, "with 8-word stacks many rays must have been parked: %d of %d" % (sh.cast_redo_rays, sh.ext_rays + sh.sh_rays)
         hip.close(); sb.close(); orc.close(); dev.close()
+
+
+def test_wide_kernel_declines_a_tree_whose_child_boxes_stick_out(pkg, device, wide, cornell_scene):
+    # the wide walk's equivalence with the reference's rests on every child box lying inside its parent's box (pt_traverse_wide.hip); a
+    # tree that violates it -- here: one child box of the Cornell tree pushed out through its parent's wall -- gets no wide copy and is
+    # walked by the binary-tree kernel, which tests every box where the reference tests it: flags say so, results equal the oracle's
+    scene = dict(cornell_scene)
+    nodes = cornell_scene["nodes"].copy()
+    inner = np.nonzero(nodes["isLeaf"] == 0)[0]
+    victim = int(nodes["left"][inner[1]])
+    nodes["max"][victim][0] = nodes["max"][inner[1]][0] + 0.75      # sticks out of its parent in +x
+    scene["nodes"] = nodes
+    W, H, P = 48, 27, 2048
+    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, scene, W, H, P)
+    for it in range(12):
+        PU.step_both(orc, hip, ocam, hcam)
+    _assert_same(orc, hip, P, P, 12)
+    st = hip.stats()
+    assert st.flags & pkg.capi.STAT_CAST_FETCH and not (st.flags & pkg.capi.STAT_CAST_WIDE), "flags %#x" % st.flags
+    assert st.wide_nodes == 0
+    hip.close(); sb.close(); orc.close()
+    # the well-formed tree of the same scene does get the wide kernel
+    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, cornell_scene, W, H, P)
+    PU.step_both(orc, hip, ocam, hcam)
+    st = hip.stats()
+    assert st.flags & pkg.capi.STAT_CAST_WIDE and st.wide_nodes > 0 and st.wide_pairs > 0
+    hip.close(); sb.close(); orc.close()
