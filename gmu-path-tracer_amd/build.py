@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libgmupt.so")
 
 DEVICE_SOURCES = ["csrc/pt_kernels.hip", "csrc/pt_traverse.hip", "csrc/pt_traverse_wide.hip", "csrc/pt_traverse_variants.hip", "csrc/gmupt_capi.hip"]   # pt_traverse_variants.hip is empty without -DGMUPT_VARIANTS
-HOST_SOURCES = ["host/sbvh_builder.cpp", "host/Camera.cpp", "host/TextureLoader.cpp"]
+HOST_SOURCES = ["host/sbvh_builder.cpp", "host/Camera.cpp", "host/TextureLoader.cpp", "host/AvirResize.cpp"]
 HEADERS = ["csrc/pt_traverse_common.hpp", "csrc/pt_traverse_deferred.hpp", "csrc/pt_kernel_util.hpp", "host/MeshData.hpp", "host/BVHWrapper.hpp", "csrc/pt_device.hpp", "csrc/detmath.hpp", "host/sbvh_builder.hpp", "host/Camera.hpp", "host/TextureLoader.hpp", "host/png_reader.hpp", "host/Constants.hpp", "../include/gmupt.h"]
 
 FLAGS = [

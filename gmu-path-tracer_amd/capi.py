@@ -267,7 +267,7 @@ def decode_png(data):
 
 
 def resize_square(rgba, new_size):
-    """Square RGBA8 resize (the reference's avir call, Scene.cpp:276-279; own Lanczos-3 filter)."""
+    """Square RGBA8 resize: the bytes of the reference's avir call (Scene.cpp:276-279; host/AvirResize.cpp restates avir's pipeline for it)."""
     rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
     assert rgba.ndim == 3 and rgba.shape[0] == rgba.shape[1] and rgba.shape[2] == 4
     out = np.empty((new_size, new_size, 4), dtype=np.uint8)

@@ -1,11 +1,9 @@
 // Texture ingestion of the host side: what Scene::loadSpecificTexture + Scene::createTextures do before the D3D11 upload
 // (reference Source/Scene.cpp:209-244 and :246-290): decode every material's PNG of one texture type to RGBA8, give it the next layer
 // index, pick the common square size by the reference's "median of the distinct byte sizes" rule and resize the other layers to it.
-// The reference resizes with the avir library (windowed-sinc filter bank, 8-bit, linear light); this build uses its own separable
-// Lanczos-3 filter on avir's sampling geometry.  Not bit-identical: measured against avir compiled from the reference tree
-// (tests/golden/texture_ref.npz, tests/test_textures_cpu.py::test_resize_against_avir_fixture) an enlarged layer is within 2 / 255 per
-// texel (mean 0.3), a reduced one within 2 in the interior and within 16 in its outermost two rows / columns.  Layers that already have
-// the common size are passed through bit for bit, as in the reference.
+// The reference resizes with the avir library; resizeSquare (AvirResize.cpp) restates avir's pipeline for that call and returns the same
+// bytes (tests/golden/texture_ref.npz, tests/test_textures_cpu.py::test_resize_against_avir_fixture).  Layers that already have the common
+// size are not resized, as in the reference (Scene.cpp:268).
 #pragma once
 #include <cstdint>
 #include <string>
@@ -23,8 +21,8 @@ struct TextureSet                                  // Scene::LoadedTextures (Inc
 // Scene.cpp:232-241: the distinct layer byte sizes in ascending order, the element at position count/2, width = sqrt(bytes / 4)
 unsigned commonDimension(const std::vector<size_t>& layerBytes);
 
-// square RGBA8 resize, separable Lanczos-3 (stretched by the reduction factor when shrinking), edge-clamped, round to nearest;
-// sampling positions as avir's default step: corner pixel centres coincide when enlarging, outer edges when reducing
+// square RGBA8 resize with the bytes of avir::CImageResizer<fpclass_float8_dil>(8).resizeImage(src, n, n, 0, dst, m, m, 4, 0)
+// (Scene.cpp:276-279); defined in AvirResize.cpp
 std::vector<uint8_t> resizeSquare(const uint8_t* rgba, unsigned oldDimension, unsigned newDimension);
 
 // encoded[i] = the PNG file of material i for this texture type (empty: none).  Sets materials[i].textureIndices[index] to the layer

@@ -108,9 +108,9 @@ int gmupt_texture_array_create(gmupt_device* dev, const uint8_t* rgba8, uint32_t
 /* Host-side image helpers for the texture path (no device work).
  * gmupt_image_decode_png replaces lodepng::decode(out, w, h, file) (Source/Scene.cpp:226): PNG file bytes -> tightly packed RGBA8;
  * *rgba is allocated by the library, release it with gmupt_image_free.
- * gmupt_image_resize_square replaces avir::CImageResizer::resizeImage on square RGBA8 layers (Scene.cpp:269-279); own Lanczos-3 filter on
- * avir's sampling geometry, within 2 / 255 of avir per texel except the outermost two rows / columns of a REDUCED layer (within 16), measured
- * against avir itself (tests/golden/texture_ref.npz); dst holds new_size * new_size * 4 bytes.
+ * gmupt_image_resize_square replaces avir::CImageResizer<fpclass_float8_dil>(8)::resizeImage(src, n, n, 0, dst, m, m, 4, 0) on square RGBA8
+ * layers (Scene.cpp:269-279): the same bytes as avir 2.4 (Include/avir/avir.h) for every size pair, pinned against avir compiled from the
+ * reference tree (tests/golden/texture_ref.npz); equal sizes run avir's filters too, they are not a copy.  dst holds new_size * new_size * 4 bytes.
  * gmupt_texture_common_size is the reference's size rule (Scene.cpp:232-241): median of the DISTINCT layer byte sizes -> width. */
 int gmupt_image_decode_png(const void* png, size_t bytes, uint32_t* width, uint32_t* height, uint8_t** rgba);
 void gmupt_image_free(uint8_t* rgba);

@@ -56,7 +56,29 @@ def layers():
         chk[..., :3] = np.where(((xx // 4 + yy // 4) % 2)[..., None] == 0, (235, 235, 235), (20, 40, 200)); chk[..., 3] = np.where(xx < size // 2, 255, 128)
         out["checker%d" % size] = chk
     out["noise32"] = rng.integers(0, 256, (32, 32, 4)).astype(np.uint8)
+    # layers of the second group (EXTRA_TARGETS): sizes at which avir picks its other filter structures
+    rng2 = np.random.default_rng(23)
+    for size in (1, 7, 37, 63):
+        out["grain%d" % size] = rng2.integers(0, 256, (size, size, 4)).astype(np.uint8)
+    yy, xx = np.mgrid[0:200, 0:200].astype(np.float64)
+    img = np.zeros((200, 200, 4), np.uint8)
+    img[..., 0] = np.round(127.5 + 127.5 * np.sin(xx * 0.9 + yy * 0.13)); img[..., 1] = np.round(255 * ((xx * yy) % 4096) / 4095)
+    img[..., 2] = np.where((xx.astype(int) ^ yy.astype(int)) & 8, 250, 5); img[..., 3] = np.round(255 * yy / 199)
+    out["waves200"] = img
     return out
+
+
+# second group: (layer, new size) pairs chosen so that the fixture holds every filter structure avir's cost model picks for this call -- both
+# interpolation orders, filter and interpolator separate and combined, a different structure for rows and columns (smooth64 -> 300), the
+# 16-fold half-band step of reductions beyond 32:1 (waves200 -> 6), equal sizes, one-texel images
+EXTRA_TARGETS = (("grain1", 7), ("grain7", 1), ("grain7", 64), ("grain37", 37), ("grain37", 100), ("grain37", 17), ("grain63", 64), ("grain63", 62),
+                 ("waves200", 128), ("waves200", 33), ("waves200", 6), ("waves200", 201), ("smooth64", 300), ("noise32", 32))
+
+
+def targets(name, size):
+    if name.startswith(("grain", "waves")):
+        return []
+    return sorted({16, 24, 32, 48, 64, 128} - {size})
 
 
 def main():
@@ -68,8 +90,10 @@ def main():
         data["decoded_" + name] = ref_decode(L, png)
         assert np.array_equal(data["decoded_" + name], img)
         size = img.shape[0]
-        for new in sorted({16, 24, 32, 48, 64, 128} - {size}):
+        for new in targets(name, size):
             data["resized_%s_to%d" % (name, new)] = ref_resize(L, img, new)
+    for name, new in EXTRA_TARGETS:
+        data["resized_%s_to%d" % (name, new)] = ref_resize(L, layers()[name], new)
     # other PNG flavours through lodepng (grey, palette + tRNS, 16 bit, interlaced): decode pins only
     rng = np.random.default_rng(5)
     for ct, depth in ((0, 8), (0, 16), (2, 16), (3, 4), (4, 8)):
@@ -83,7 +107,7 @@ def main():
     path = os.path.join(ROOT, "tests", "golden", "texture_ref.npz")
     np.savez_compressed(path, **data)
     print("wrote %s: %d arrays, %d bytes" % (path, len(data), os.path.getsize(path)))
-    # how far is the product's own resize from avir?
+    # the product's resize against avir (a restatement of avir's pipeline: every line must say 0)
     capi = gmupt_pkg.load().capi
     for k in sorted(data):
         if k.startswith("resized_"):

@@ -17,7 +17,7 @@ def main(per_file=120):
     exe = os.path.join(tmp, "loader_fuzz")
     host = os.path.join(ROOT, "gmu-path-tracer_amd", "host")
     subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-ffp-contract=off", "-o", exe,
-                    os.path.join(HERE, "loader_fuzz.cpp")] + [os.path.join(host, f) for f in ("GltfLoader.cpp", "MeshData.cpp", "TextureLoader.cpp", "SceneParams.cpp")], check=True)
+                    os.path.join(HERE, "loader_fuzz.cpp")] + [os.path.join(host, f) for f in ("GltfLoader.cpp", "MeshData.cpp", "TextureLoader.cpp", "AvirResize.cpp", "SceneParams.cpp")], check=True)
     written = pkg.scenes.save_gltf(pkg.scenes.textured_mesh(), os.path.join(tmp, "s.gltf"), texture_scale={(0, 0): 2})
     pkg.scenes.gltf_to_glb(os.path.join(tmp, "s.gltf"), os.path.join(tmp, "packed.glb"))
     pkg.scenes.save_gmesh(pkg.scenes.cornell_mesh(), os.path.join(tmp, "c.gmesh"), os.path.join(tmp, "c.params"))

@@ -23,7 +23,7 @@ int main(int argc, char** argv)
                 std::ifstream f(path, std::ios::binary);
                 std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
                 const gmupt::png::Image img = gmupt::png::decode(bytes.data(), bytes.size());
-                if (img.width == img.height && img.width && img.width <= 512) (void)gmupt::resizeSquare(img.rgba.data(), img.width, 24);
+                if (img.width == img.height && img.width && img.width <= 512) for (unsigned to : { 24u, 1u, 7u, img.width, img.width + 1, img.width * 2 + 3 }) (void)gmupt::resizeSquare(img.rgba.data(), img.width, to);   // every filter structure of AvirResize.cpp under the sanitizers
             } else if (endsWith(path, ".params")) {
                 (void)SceneParams::load(path);
             } else {
