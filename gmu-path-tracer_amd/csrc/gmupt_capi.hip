@@ -595,7 +595,7 @@ static int build_traversal_copy(gmupt_renderer* r, const gmupt_buffer* nodesB, c
             for (int k = 0; k < 4; k++) {
                 if (k < w.n) {
                     const gmupt_bvh_node& b = nodes[(size_t)w.s[k]];
-                    for (int a = 0; a < 3; a++) { o.p[a][k] = b.min[a]; o.p[3 + a][k] = b.max[a]; }
+                    for (int a = 0; a < 3; a++) { o.p[a][k] = b.min[a]; o.p[5 - a][k] = b.max[a]; }   // rows: min x, y, z, max z, y, x
                     o.link[k] = b.isLeaf ? ~leafPair[(size_t)w.s[k]] : number[(size_t)createdOf[(size_t)w.s[k]]];
                 } else {
                     for (int a = 0; a < 6; a++) o.p[a][k] = qnan;      // never hit

@@ -99,7 +99,8 @@ static_assert(sizeof(Node64) == 64 && sizeof(Tri48) == 48, "packed traversal rec
 // memory-side read of this chip.  Up to four descendants of one inner node of the binary tree (its two children, the inner ones among
 // them replaced by THEIR children, largest surface area first, until four slots are taken), plane by plane so that the four slab tests
 // of a step are 4-wide vector arithmetic:
-//   p[0] = min.x of slots 0..3   p[1] = min.y   p[2] = min.z   p[3] = max.x   p[4] = max.y   p[5] = max.z   (an empty slot is all NaN: never hit)
+//   p[0] = min.x of slots 0..3   p[1] = min.y   p[2] = min.z   p[3] = max.z   p[4] = max.y   p[5] = max.x   (an empty slot is all NaN: never hit;
+//   the two planes of an axis are rows a and 5 - a: a ray fetches them in the order it meets them with ONE constant, row + other row = 5)
 //   link[k] >= 0: index of the WNode of that descendant; < 0: leaf whose first triangle record is ~link[k]; kDone in an empty slot
 //   aux[0] = depth of the node in the binary tree, aux[1] = number of occupied slots
 struct alignas(128) WNode { float p[6][4]; int32_t link[4]; int32_t aux[4]; };

@@ -448,6 +448,9 @@ __device__ __forceinline__ void stage_new_path(const RenderParams& p, uint32_t q
     p.queues[(size_t)Q_EXT_RAY * p.P + queueIndex] = index;                  // :51
 }
 
+#ifndef GMUPT_MATERIAL_REGROUP
+#define GMUPT_MATERIAL_REGROUP 1
+#endif
 __global__ __launch_bounds__(kBlock) void k_material(RenderParams p, int clearFrame)
 {
     __shared__ uint32_t s_cnt[kNumCounts][kBlock / 64];
@@ -511,6 +514,42 @@ __global__ __launch_bounds__(kBlock) void k_material(RenderParams p, int clearFr
             if (!clearFrame) { st->pathsCompleted += nEnded; st->segments += (unsigned long long)nEnded + nUE4 + nGlass; }
         }
     }
+#if GMUPT_MATERIAL_REGROUP
+    // ---- the slots of the block regrouped by class before the stages run: thread j takes the j-th slot of the sequence (UE4 slots in slot order,
+    // then glass, then ended).  The three stages are long and different (k_material is bound by VALU issue, not by memory): with the classes
+    // mixed as the slots are, nearly every wave runs all three one after the other at 63 % of its lanes; regrouped, at most two waves of a block
+    // hold more than one class.  Nothing a slot computes depends on the thread that computes it: rank and slot are handed over with it.
+    __shared__ uint16_t s_item[kBlock], s_srank[kBlock];
+    uint32_t nBlk[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { uint32_t n = 0; for (uint32_t w = 0; w < kBlock / 64; w++) n += s_cnt[k][w]; nBlk[k] = n; }
+    if (c <= CLS_ENDED) {
+        // local rank = slots of the same class with a smaller index in this block: earlier waves + lower lanes
+        const unsigned long long mine = (c == CLS_UE4) ? b0 : (c == CLS_GLASS) ? b1 : b2;
+        uint32_t local = prefix_rank(mine);
+        for (uint32_t w = 0; w < wave; w++) local += s_cnt[c][w];
+        uint32_t slocal = 0;
+        if (shadow) { slocal = prefix_rank(b3); for (uint32_t w = 0; w < wave; w++) slocal += s_cnt[3][w]; }
+        const uint32_t j = (c == CLS_UE4 ? 0u : c == CLS_GLASS ? nBlk[CLS_UE4] : nBlk[CLS_UE4] + nBlk[CLS_GLASS]) + local;
+        s_item[j] = (uint16_t)(threadIdx.x | ((uint32_t)c << 12) | (shadow ? 0x8000u : 0u));
+        s_srank[j] = (uint16_t)slocal;
+    }
+    __syncthreads();
+    if (threadIdx.x >= nBlk[0] + nBlk[1] + nBlk[2]) return;
+    const uint32_t item = s_item[threadIdx.x];
+    const int cj = (int)((item >> 12) & 7u);
+    const uint32_t slot = blockIdx.x * kBlock + (item & 0xFFFu);
+    // rank = slots of the same class with a smaller index: block offset + position inside the block's run of that class
+    const uint32_t rank = s_pre[cj] + threadIdx.x - (cj == CLS_UE4 ? 0u : cj == CLS_GLASS ? nBlk[CLS_UE4] : nBlk[CLS_UE4] + nBlk[CLS_GLASS]);
+
+    if (cj == CLS_ENDED) stage_new_path(p, rank, slot, clearFrame);
+    else {
+        p.queues[(size_t)(cj == CLS_UE4 ? Q_MAT_UE4 : Q_MAT_GLASS) * p.P + rank] = slot; // logic.hlsl:282-285
+        if (cj == CLS_UE4) stage_ue4(p, rank, slot, (item & 0x8000u) ? s_pre[3] + s_srank[threadIdx.x] : 0u, extUE4Offset);
+        else stage_glass(p, rank, slot, extGlassOffset);
+    }
+}
+#else
     if (c > CLS_ENDED) return;
     // rank = slots of the same class with a smaller index: block offset + earlier waves + lower lanes
     const unsigned long long mine = (c == CLS_UE4) ? b0 : (c == CLS_GLASS) ? b1 : b2;
@@ -530,6 +569,7 @@ __global__ __launch_bounds__(kBlock) void k_material(RenderParams p, int clearFr
         } else stage_glass(p, rank, i, extGlassOffset);
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------ detmath probe
 __global__ void k_detmath(int fn, const float* x, const float* y, float* out, uint32_t n)

@@ -44,6 +44,9 @@ namespace gmupt {
 #ifndef GMUPT_WIDE_PARK
 #define GMUPT_WIDE_PARK 16
 #endif
+#ifndef GMUPT_WIDE_SIGNED
+#define GMUPT_WIDE_SIGNED 1     // planes fetched in ray-sign order, ordered slab tree unless a walking ray of the wave has a special 1 / d
+#endif
 constexpr int kWideStack = GMUPT_WIDE_STACK;   // LDS words per lane shared by the two stacks
 constexpr int kWideTop = GMUPT_WIDE_TOP;       // WNodes of the tree top kept in LDS
 constexpr int kWideRoom = 4;                   // a node step pushes at most four entries
@@ -57,7 +60,7 @@ typedef int vec4i __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void load_wnode_lds(const float4* s_top, int cur, vec4f& q0, vec4f& q1, vec4f& q2, vec4f& q3, vec4f& q4, vec4f& q5, vec4i& lk)
 {
     const GMUPT_AS_LDS vec4f* n = (const GMUPT_AS_LDS vec4f*)(s_top) + cur * 8;
-    q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = n[3]; q4 = n[4]; q5 = n[5]; lk = *(const GMUPT_AS_LDS vec4i*)(n + 6);
+    q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = n[5]; q4 = n[4]; q5 = n[3]; lk = *(const GMUPT_AS_LDS vec4i*)(n + 6);   // rows: min x, y, z, max z, y, x
 }
 __device__ __forceinline__ void load_wnode_glb(__amdgpu_buffer_rsrc_t nodes, int cur, vec4f& q0, vec4f& q1, vec4f& q2, vec4f& q3, vec4f& q4, vec4f& q5, vec4i& lk)
 {
@@ -65,10 +68,43 @@ __device__ __forceinline__ void load_wnode_glb(__amdgpu_buffer_rsrc_t nodes, int
     q0 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off, 0, 0));
     q1 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 16, 0, 0));
     q2 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 32, 0, 0));
-    q3 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 48, 0, 0));
+    q3 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 80, 0, 0));
     q4 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 64, 0, 0));
-    q5 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 80, 0, 0));
+    q5 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 48, 0, 0));
     lk = __builtin_bit_cast(vec4i, __builtin_amdgcn_raw_buffer_load_b128(nodes, off + 96, 0, 0));
+}
+
+// The planes of a WNode in RAY-SIGN order: q0 .. q2 = the plane of each axis the ray meets first (row `axis` for a positive, row 5 - axis for a
+// negative 1 / d), q3 .. q5 = the other one.  Which row is a per-lane byte offset (RayPk's packed `sg`: bytes 0..2 = 0|80, 16|64, 32|48), added to
+// the lane's record address with one SDWA add per axis; the far row of every axis is at (2 * record + 80) - near address.
+__device__ __forceinline__ uint32_t add_byte0(uint32_t a, uint32_t b) { uint32_t r; asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ uint32_t add_byte1(uint32_t a, uint32_t b) { uint32_t r; asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ uint32_t add_byte2(uint32_t a, uint32_t b) { uint32_t r; asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+struct PlaneAddr { uint32_t nx, ny, nz, fx, fy, fz, rec; };
+__device__ __forceinline__ PlaneAddr plane_addresses(int cur, uint32_t sg)
+{
+    PlaneAddr a; a.rec = (uint32_t)cur * 128u;
+    const uint32_t k2 = a.rec * 2u + 80u;
+    a.nx = add_byte0(a.rec, sg); a.ny = add_byte1(a.rec, sg); a.nz = add_byte2(a.rec, sg);
+    a.fx = k2 - a.nx; a.fy = k2 - a.ny; a.fz = k2 - a.nz;
+    return a;
+}
+__device__ __forceinline__ void load_wnode_lds_signed(const float4* s_top, const PlaneAddr a, vec4f& q0, vec4f& q1, vec4f& q2, vec4f& q3, vec4f& q4, vec4f& q5, vec4i& lk)
+{
+    const uint32_t base = (uint32_t)(uintptr_t)((const GMUPT_AS_LDS vec4f*)(s_top));     // 0: the top is the first thing in LDS
+    q0 = *(const GMUPT_AS_LDS vec4f*)(uintptr_t)(base + a.nx); q1 = *(const GMUPT_AS_LDS vec4f*)(uintptr_t)(base + a.ny); q2 = *(const GMUPT_AS_LDS vec4f*)(uintptr_t)(base + a.nz);
+    q3 = *(const GMUPT_AS_LDS vec4f*)(uintptr_t)(base + a.fx); q4 = *(const GMUPT_AS_LDS vec4f*)(uintptr_t)(base + a.fy); q5 = *(const GMUPT_AS_LDS vec4f*)(uintptr_t)(base + a.fz);
+    lk = *(const GMUPT_AS_LDS vec4i*)(uintptr_t)(base + a.rec + 96u);
+}
+__device__ __forceinline__ void load_wnode_glb_signed(__amdgpu_buffer_rsrc_t nodes, const PlaneAddr a, vec4f& q0, vec4f& q1, vec4f& q2, vec4f& q3, vec4f& q4, vec4f& q5, vec4i& lk)
+{
+    q0 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, (int)a.nx, 0, 0));
+    q1 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, (int)a.ny, 0, 0));
+    q2 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, (int)a.nz, 0, 0));
+    q3 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, (int)a.fx, 0, 0));
+    q4 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, (int)a.fy, 0, 0));
+    q5 = __builtin_bit_cast(vec4f, __builtin_amdgcn_raw_buffer_load_b128(nodes, (int)a.fz, 0, 0));
+    lk = __builtin_bit_cast(vec4i, __builtin_amdgcn_raw_buffer_load_b128(nodes, (int)a.rec + 96, 0, 0));
 }
 
 // the slab test of ray_box (extensionRayCast.hlsl:79-94) on one slot; "hit" is `result > 0`, i.e. t1 >= t0 and (t0 > 0 ? t0 : t1) > 0,
@@ -116,15 +152,24 @@ __device__ __forceinline__ float v_max(float a, float b) { float r; asm("v_max_f
 __device__ __forceinline__ float v_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float v_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
-// The lane's ray in five aligned register pairs: (o.x, o.y), (o.z, 1/d.z), (1/d.x, 1/d.y), (d.x, d.y), (d.z, -)
+// The lane's ray in five aligned register pairs: (o.x, o.y), (o.z, 1/d.z), (1/d.x, 1/d.y), (d.x, d.y), (d.z, sg).  sg (raw bits): byte k = the byte
+// offset of the plane row the ray meets first on axis k (load_wnode_*_signed), byte 3 = 1 when a component of 1 / d is infinite or NaN
+// (a direction component that is zero, denormal or NaN): for such a ray (plane - o) * (1 / d) can be NaN, and min / max decide which plane
+// is the near one -- the wave then takes the general form of the test.
 struct RayPk { vec2f oxy, ozi, ixy, dxy, dzz; };
+__device__ __forceinline__ uint32_t ray_sg(const RayPk& r) { return __builtin_bit_cast(vec2u, r.dzz).y; }
 __device__ __forceinline__ f3 ray_o(const RayPk& r) { return mk3(r.oxy.x, r.oxy.y, r.ozi.x); }
 __device__ __forceinline__ f3 ray_inv(const RayPk& r) { return mk3(r.ixy.x, r.ixy.y, r.ozi.y); }
 __device__ __forceinline__ f3 ray_d(const RayPk& r) { return mk3(r.dxy.x, r.dxy.y, r.dzz.x); }
 __device__ __forceinline__ void ray_set(RayPk& r, f3 o, f3 d)
 {
     r.oxy.x = o.x; r.oxy.y = o.y; r.ozi.x = o.z; r.ixy.x = 1.0f / d.x; r.ixy.y = 1.0f / d.y; r.ozi.y = 1.0f / d.z;
-    r.dxy.x = d.x; r.dxy.y = d.y; r.dzz.x = d.z; r.dzz.y = 0.0f;
+    r.dxy.x = d.x; r.dxy.y = d.y; r.dzz.x = d.z;
+    const vec2u ib = __builtin_bit_cast(vec2u, r.ixy), zb = __builtin_bit_cast(vec2u, r.ozi);      // (whole-vector casts: a bit cast of a vector ELEMENT reads element 0)
+    const uint32_t bx = ib.x, by = ib.y, bz = zb.y;
+    const bool special = ((bx & 0x7F800000u) == 0x7F800000u) | ((by & 0x7F800000u) == 0x7F800000u) | ((bz & 0x7F800000u) == 0x7F800000u);
+    const uint32_t sg = ((bx >> 31) ? 80u : 0u) | ((by >> 31) ? (64u << 8) : (16u << 8)) | ((bz >> 31) ? (48u << 16) : (32u << 16)) | (special ? (1u << 24) : 0u);
+    vec2u dz = __builtin_bit_cast(vec2u, r.dzz); dz.y = sg; r.dzz = __builtin_bit_cast(vec2f, dz);
 }
 
 #define GMUPT_LO(Q) __builtin_shufflevector(Q, Q, 0, 1)
@@ -135,9 +180,18 @@ __device__ __forceinline__ bool slab_hit_pk(float nx, float ny, float nz, float 
     const float t0 = v_max3(v_min(fx, nx), v_min(fy, ny), v_min(fz, nz));
     return (t1 >= t0) & (t1 > 0.0f);
 }
+// the same test when the near / far plane of every axis is known (rows in ray-sign order, 1 / d finite): (near - o) / d <= (far - o) / d by the
+// monotonicity of the two rounded operations, so min(f, n) IS n and max(f, n) IS f -- six of the eight min / max of a slot go
+__device__ __forceinline__ bool slab_hit_ordered(float nx, float ny, float nz, float fx, float fy, float fz)
+{
+    const float t1 = v_min3(fx, fy, fz);
+    const float t0 = v_max3(nx, ny, nz);
+    return (t1 >= t0) & (t1 > 0.0f);
+}
 // the four slab tests of a step: (plane - o) * (1 / d) for two slots per packed instruction, then the min / max tree of ray_box per slot
+// (GENERAL: wave-uniform; the rows may be in either order for it)
 __device__ __forceinline__ void slab_hits4(const vec4f q0, const vec4f q1, const vec4f q2, const vec4f q3, const vec4f q4, const vec4f q5, const RayPk& ray,
-                                           bool& h0, bool& h1, bool& h2, bool& h3)
+                                           bool& h0, bool& h1, bool& h2, bool& h3, const bool general = true)
 {
 #if GMUPT_WIDE_PK
     const vec2f nxa = pk_mul_lo(pk_sub_lo(GMUPT_LO(q0), ray.oxy), ray.ixy), nxb = pk_mul_lo(pk_sub_lo(GMUPT_HI(q0), ray.oxy), ray.ixy);
@@ -146,8 +200,13 @@ __device__ __forceinline__ void slab_hits4(const vec4f q0, const vec4f q1, const
     const vec2f fxa = pk_mul_lo(pk_sub_lo(GMUPT_LO(q3), ray.oxy), ray.ixy), fxb = pk_mul_lo(pk_sub_lo(GMUPT_HI(q3), ray.oxy), ray.ixy);
     const vec2f fya = pk_mul_hi(pk_sub_hi(GMUPT_LO(q4), ray.oxy), ray.ixy), fyb = pk_mul_hi(pk_sub_hi(GMUPT_HI(q4), ray.oxy), ray.ixy);
     const vec2f fza = pk_mul_hi(pk_sub_lo(GMUPT_LO(q5), ray.ozi), ray.ozi), fzb = pk_mul_hi(pk_sub_lo(GMUPT_HI(q5), ray.ozi), ray.ozi);
-    h0 = slab_hit_pk(nxa.x, nya.x, nza.x, fxa.x, fya.x, fza.x); h1 = slab_hit_pk(nxa.y, nya.y, nza.y, fxa.y, fya.y, fza.y);
-    h2 = slab_hit_pk(nxb.x, nyb.x, nzb.x, fxb.x, fyb.x, fzb.x); h3 = slab_hit_pk(nxb.y, nyb.y, nzb.y, fxb.y, fyb.y, fzb.y);
+    if (general) {
+        h0 = slab_hit_pk(nxa.x, nya.x, nza.x, fxa.x, fya.x, fza.x); h1 = slab_hit_pk(nxa.y, nya.y, nza.y, fxa.y, fya.y, fza.y);
+        h2 = slab_hit_pk(nxb.x, nyb.x, nzb.x, fxb.x, fyb.x, fzb.x); h3 = slab_hit_pk(nxb.y, nyb.y, nzb.y, fxb.y, fyb.y, fzb.y);
+    } else {
+        h0 = slab_hit_ordered(nxa.x, nya.x, nza.x, fxa.x, fya.x, fza.x); h1 = slab_hit_ordered(nxa.y, nya.y, nza.y, fxa.y, fya.y, fza.y);
+        h2 = slab_hit_ordered(nxb.x, nyb.x, nzb.x, fxb.x, fyb.x, fzb.x); h3 = slab_hit_ordered(nxb.y, nyb.y, nzb.y, fxb.y, fyb.y, fzb.y);
+    }
 #else
     const f3 o = ray_o(ray), invdir = ray_inv(ray);
     h0 = slab_hit(q0.x, q1.x, q2.x, q3.x, q4.x, q5.x, o, invdir); h1 = slab_hit(q0.y, q1.y, q2.y, q3.y, q4.y, q5.y, o, invdir);
@@ -199,8 +258,11 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
 {
     constexpr int S = kWideStack;
     constexpr int REPS = GMUPT_WIDE_REPS;
-    __shared__ int s_stack[S * kDefBlock];
-    __shared__ float4 s_top[kWideTop * 8];
+    // one LDS object, the tree top first: a top node's LDS address is then its byte offset in the node table (cur * 128), and the plane
+    // addresses of a step (load_wnode_*_signed) serve the LDS and the vector-memory fetch alike
+    __shared__ float4 s_lds[kWideTop * 8 + S * kDefBlock / 4];
+    float4* s_top = s_lds;
+    int* s_stack = reinterpret_cast<int*>(s_lds + kWideTop * 8);
     {
         const float4* src = reinterpret_cast<const float4*>(p.trav.wnodes);
         for (uint32_t k = threadIdx.x; k < p.trav.wideTopCount * 8u; k += kDefBlock) s_top[k] = src[k];
@@ -475,10 +537,19 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
             census0 += __popcll(__ballot(cur == kDone && !pendingNow)); census1 += __popcll(__ballot(cur >= 0 && roomNow));
             census2 += __popcll(__ballot(cur >= 0 && !roomNow)); census3 += __popcll(__ballot(cur == kDone && pendingNow));
         }
+        // (wave-uniform, once per iteration: rays only change in the refill above) the ordered slab tree needs every walking ray's 1 / d finite
+        const bool generalSlabs = !GMUPT_WIDE_SIGNED || __ballot(cur >= 0 && (ray_sg(ray) >> 24) != 0u) != 0ull;
 #pragma unroll
         for (int rep = 0; rep < REPS; rep++) {
 #ifndef GMUPT_WIDE_TOPSTEPS
 #define GMUPT_WIDE_TOPSTEPS 0   // (measured: 1 -> +6 %, 2 -> +18 % of the launch time: the kernel is bound by instruction issue, not by the round trip)
+#endif
+#if GMUPT_WIDE_SIGNED
+#define GMUPT_WIDE_LOAD_LDS() load_wnode_lds_signed(s_top, pla, q0, q1, q2, q3, q4, q5, lk)
+#define GMUPT_WIDE_LOAD_GLB() load_wnode_glb_signed(rNodes, pla, q0, q1, q2, q3, q4, q5, lk)
+#else
+#define GMUPT_WIDE_LOAD_LDS() load_wnode_lds(s_top, cur, q0, q1, q2, q3, q4, q5, lk)
+#define GMUPT_WIDE_LOAD_GLB() load_wnode_glb(rNodes, cur, q0, q1, q2, q3, q4, q5, lk)
 #endif
             // the four slab tests of the node in q0 .. lk, then: the first hit inner slot is the next node, the other hits are pushed (inner nodes from the
             // bottom, leaves from the top) -- ranks by prefix counts, one predicated LDS store per slot and stack (nested regions per slot: the same time)
@@ -486,7 +557,7 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
             { if (STATS) { if (kind == 0) tcE.inner++; else tcS.inner++; if (prefix_rank(__ballot(1)) == 0) { if (phase == 0) wInE++; else wInS++; } \
                            if (INTOP) { if (kind == 0) topE++; else topS++; } boxes += (uint32_t)ts.wnodes[cur].aux[1]; } \
               bool h0, h1, h2, h3; \
-              slab_hits4(q0, q1, q2, q3, q4, q5, ray, h0, h1, h2, h3); \
+              slab_hits4(q0, q1, q2, q3, q4, q5, ray, h0, h1, h2, h3, generalSlabs); \
               const bool i0 = h0 & (lk.x >= 0), i1 = h1 & (lk.y >= 0), i2 = h2 & (lk.z >= 0), i3 = h3 & (lk.w >= 0); \
               const bool f0 = h0 & (lk.x < 0), f1 = h1 & (lk.y < 0), f2 = h2 & (lk.z < 0), f3_ = h3 & (lk.w < 0); \
               const uint32_t r1 = i0 ? 1u : 0u, r2 = r1 + (i1 ? 1u : 0u), r3 = r2 + (i2 ? 1u : 0u), cI = r3 + (i3 ? 1u : 0u);   /* inner hits before slot k */ \
@@ -509,16 +580,18 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
 #pragma unroll
             for (int ts_ = 0; ts_ < GMUPT_WIDE_TOPSTEPS; ts_++) {
                 if (cur >= 0 && (uint32_t)cur < topCount && pb >= pa && pb - pa >= (uint32_t)(kWideRoom - 1)) {
-                    load_wnode_lds(s_top, cur, q0, q1, q2, q3, q4, q5, lk);
+                    const PlaneAddr pla = plane_addresses(cur, ray_sg(ray)); (void)pla;
+                    GMUPT_WIDE_LOAD_LDS();
                     GMUPT_WIDE_NODE_COMPUTE(true)
                 }
             }
             // fetch phase
             const bool doNode = cur >= 0 && pb >= pa && pb - pa >= (uint32_t)(kWideRoom - 1);
             const bool inTop = (uint32_t)cur < topCount;
-            if (doNode && inTop) load_wnode_lds(s_top, cur, q0, q1, q2, q3, q4, q5, lk);
+            const PlaneAddr pla = plane_addresses(cur, ray_sg(ray)); (void)pla;    // (for every lane: the node-less ones load nothing)
+            if (doNode && inTop) GMUPT_WIDE_LOAD_LDS();
             asm volatile("" ::: "memory");   // LDS lanes first, see load_node
-            if (doNode && !inTop) load_wnode_glb(rNodes, cur, q0, q1, q2, q3, q4, q5, lk);
+            if (doNode && !inTop) GMUPT_WIDE_LOAD_GLB();
             if (burst && ti < 0 && pb != (uint32_t)(S - 1)) { pb++; ti = ~sl[pb * kDefBlock]; }
             const bool doTri = burst && ti >= 0;
             vec4f a0, a1, a2, a3, a4;                        // defined for the doTri lanes only: the TriPair of this step
@@ -559,6 +632,8 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
 #undef GMUPT_WIDE_MERGE_OWN
 #undef GMUPT_WIDE_FINISH
 #undef GMUPT_WIDE_NODE_COMPUTE
+#undef GMUPT_WIDE_LOAD_LDS
+#undef GMUPT_WIDE_LOAD_GLB
     if (STATS) { flush_counts(p.stats, tcE, raysE, true); flush_wave_iters(p.stats, wInE, wTrE, true);
                  flush_counts(p.stats, tcS, raysS, false); flush_wave_iters(p.stats, wInS, wTrS, false);
                  flush_sum(&p.stats->extTopInner, topE); flush_sum(&p.stats->shTopInner, topS); flush_sum(&p.stats->castHelperSubtrees, helped);
