@@ -62,7 +62,8 @@ class Stats(C.Structure):
                 ("cast_drain_ticks", C.c_uint64), ("cast_drain_iters", C.c_uint64), ("cast_drain_busy_lanes", C.c_uint64),
                 ("cast_wave_end_hist", C.c_uint64 * 32), ("ray_inner_hist", C.c_uint64 * 32),
                 ("ext_top_inner", C.c_uint64), ("sh_top_inner", C.c_uint64), ("cast_helper_subtrees", C.c_uint64),
-                ("cast_nested_helpers", C.c_uint64), ("cast_redo_rays", C.c_uint64), ("wide_nodes", C.c_uint64), ("wide_top_nodes", C.c_uint64), ("wide_stack_bound", C.c_uint64), ("wide_pairs", C.c_uint64), ("wide_pair_fetches", C.c_uint64), ("wide_box_tests", C.c_uint64)]
+                ("cast_nested_helpers", C.c_uint64), ("cast_redo_rays", C.c_uint64), ("wide_nodes", C.c_uint64), ("wide_top_nodes", C.c_uint64), ("wide_stack_bound", C.c_uint64), ("wide_pairs", C.c_uint64), ("wide_pair_fetches", C.c_uint64), ("wide_box_tests", C.c_uint64),
+                ("wide_iterations", C.c_uint64), ("wide_general_iterations", C.c_uint64)]
 
     def as_dict(self):
         return {n: (list(getattr(self, n)) if hasattr(getattr(self, n), "__len__") else getattr(self, n)) for n, _ in self._fields_}

@@ -884,7 +884,7 @@ extern "C" int gmupt_get_stats(gmupt_renderer* r, gmupt_stats* out)
     out->cast_waves = ds.castWaves; out->cast_wave_ticks = ds.castWaveClocks; out->cast_wave_ticks_max = ds.castWaveClocksMax;
     out->cast_drain_ticks = ds.castDrainClocks; out->cast_drain_iters = ds.castDrainIters; out->cast_drain_busy_lanes = ds.castDrainBusyLanes;
     out->ext_top_inner = ds.extTopInner; out->sh_top_inner = ds.shTopInner; out->cast_helper_subtrees = ds.castHelperSubtrees;
-    out->cast_nested_helpers = ds.castNestedHelpers; out->cast_redo_rays = ds.castRedoRays; out->wide_nodes = r->p.trav.wideCount; out->wide_top_nodes = r->p.trav.wideTopCount; out->wide_stack_bound = r->p.trav.wideStackBound; out->wide_pairs = r->p.trav.numPairs; out->wide_pair_fetches = ds.widePairFetches; out->wide_box_tests = ds.wideBoxTests;
+    out->cast_nested_helpers = ds.castNestedHelpers; out->cast_redo_rays = ds.castRedoRays; out->wide_nodes = r->p.trav.wideCount; out->wide_top_nodes = r->p.trav.wideTopCount; out->wide_stack_bound = r->p.trav.wideStackBound; out->wide_pairs = r->p.trav.numPairs; out->wide_pair_fetches = ds.widePairFetches; out->wide_box_tests = ds.wideBoxTests; out->wide_iterations = ds.wideIters; out->wide_general_iterations = ds.wideGeneralIters;
     out->ext_wave_inner = ds.extWaveInner; out->ext_wave_tris = ds.extWaveTris; out->sh_wave_inner = ds.shWaveInner; out->sh_wave_tris = ds.shWaveTris;
     if (ds.stackOverflow & 3u) return fail(GMUPT_ERR_CAST_FAULT, "gmupt_get_stats: a ray-cast launch flagged its results as invalid (flags %#x; the statistics are filled in)", out->flags);
     return GMUPT_OK;

@@ -65,6 +65,7 @@ struct DevStats {
     unsigned long long castRedoRays;            // wide ray cast: rays walked again in the reference's binary order (closest hit an exact tie between two triangles; a full stack)
     unsigned long long widePairFetches;         // wide ray cast, collect_stats: 80-byte TriPair records fetched (a leaf of n references takes ceil(n / 2))
     unsigned long long wideBoxTests;            // wide ray cast, collect_stats: occupied box slots tested
+    unsigned long long wideIters, wideGeneralIters; // wide ray cast, collect_stats: iterations of a wave (six steps each); of those: with the general slab test (a walking ray with an infinite / NaN 1 / d component)
     uint32_t activePaths;
     uint32_t stackOverflow; // bit 0: traversal needed more than the provisioned stack (results then differ from an unbounded stack); bit 1: a wave of the fused ray cast left at its iteration limit
 };

@@ -44,6 +44,12 @@ namespace gmupt {
 #ifndef GMUPT_WIDE_PARK
 #define GMUPT_WIDE_PARK 16
 #endif
+#ifndef GMUPT_WIDE_QUADPK
+#define GMUPT_WIDE_QUADPK 1     // the packed slab arithmetic one plane row per asm statement (four operations per wait state)
+#endif
+#ifndef GMUPT_WIDE_QUADTRI
+#define GMUPT_WIDE_QUADTRI 1    // the same for the triangle-pair arithmetic (four statements)
+#endif
 #ifndef GMUPT_WIDE_SIGNED
 #define GMUPT_WIDE_SIGNED 1     // planes fetched in ray-sign order, ordered slab tree unless a walking ray of the wave has a special 1 / d
 #endif
@@ -193,13 +199,30 @@ __device__ __forceinline__ bool slab_hit_ordered(float nx, float ny, float nz, f
 __device__ __forceinline__ void slab_hits4(const vec4f q0, const vec4f q1, const vec4f q2, const vec4f q3, const vec4f q4, const vec4f q5, const RayPk& ray,
                                            bool& h0, bool& h1, bool& h2, bool& h3, const bool general = true)
 {
-#if GMUPT_WIDE_PK
+#if GMUPT_WIDE_PK && GMUPT_WIDE_QUADPK
+    // one plane row (four slots) per statement: two subtractions, two multiplications -- a product is read two instructions after its
+    // difference was written, so one wait state at the end covers the statement (4 instead of 1 packed operations per `s_nop`)
+    vec2f nxa, nxb, nya, nyb, nza, nzb, fxa, fxb, fya, fyb, fza, fzb;
+#define GMUPT_ROW(A, B, Q, O, OSEL, INV, ISEL) \
+    asm("v_pk_add_f32 %0, %2, %4 " OSEL " neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %1, %3, %4 " OSEL " neg_lo:[0,1] neg_hi:[0,1]\n\t" \
+        "v_pk_mul_f32 %0, %0, %5 " ISEL "\n\tv_pk_mul_f32 %1, %1, %5 " ISEL "\n\ts_nop 0" \
+        : "=&v"(A), "=&v"(B) : "v"(GMUPT_LO(Q)), "v"(GMUPT_HI(Q)), "v"(O), "v"(INV))
+    GMUPT_ROW(nxa, nxb, q0, ray.oxy, "op_sel_hi:[1,0]", ray.ixy, "op_sel_hi:[1,0]");
+    GMUPT_ROW(nya, nyb, q1, ray.oxy, "op_sel:[0,1]", ray.ixy, "op_sel:[0,1]");
+    GMUPT_ROW(nza, nzb, q2, ray.ozi, "op_sel_hi:[1,0]", ray.ozi, "op_sel:[0,1]");
+    GMUPT_ROW(fxa, fxb, q3, ray.oxy, "op_sel_hi:[1,0]", ray.ixy, "op_sel_hi:[1,0]");
+    GMUPT_ROW(fya, fyb, q4, ray.oxy, "op_sel:[0,1]", ray.ixy, "op_sel:[0,1]");
+    GMUPT_ROW(fza, fzb, q5, ray.ozi, "op_sel_hi:[1,0]", ray.ozi, "op_sel:[0,1]");
+#undef GMUPT_ROW
+#elif GMUPT_WIDE_PK
     const vec2f nxa = pk_mul_lo(pk_sub_lo(GMUPT_LO(q0), ray.oxy), ray.ixy), nxb = pk_mul_lo(pk_sub_lo(GMUPT_HI(q0), ray.oxy), ray.ixy);
     const vec2f nya = pk_mul_hi(pk_sub_hi(GMUPT_LO(q1), ray.oxy), ray.ixy), nyb = pk_mul_hi(pk_sub_hi(GMUPT_HI(q1), ray.oxy), ray.ixy);
     const vec2f nza = pk_mul_hi(pk_sub_lo(GMUPT_LO(q2), ray.ozi), ray.ozi), nzb = pk_mul_hi(pk_sub_lo(GMUPT_HI(q2), ray.ozi), ray.ozi);
     const vec2f fxa = pk_mul_lo(pk_sub_lo(GMUPT_LO(q3), ray.oxy), ray.ixy), fxb = pk_mul_lo(pk_sub_lo(GMUPT_HI(q3), ray.oxy), ray.ixy);
     const vec2f fya = pk_mul_hi(pk_sub_hi(GMUPT_LO(q4), ray.oxy), ray.ixy), fyb = pk_mul_hi(pk_sub_hi(GMUPT_HI(q4), ray.oxy), ray.ixy);
     const vec2f fza = pk_mul_hi(pk_sub_lo(GMUPT_LO(q5), ray.ozi), ray.ozi), fzb = pk_mul_hi(pk_sub_lo(GMUPT_HI(q5), ray.ozi), ray.ozi);
+#endif
+#if GMUPT_WIDE_PK
     if (general) {
         h0 = slab_hit_pk(nxa.x, nya.x, nza.x, fxa.x, fya.x, fza.x); h1 = slab_hit_pk(nxa.y, nya.y, nza.y, fxa.y, fya.y, fza.y);
         h2 = slab_hit_pk(nxb.x, nyb.x, nzb.x, fxb.x, fyb.x, fzb.x); h3 = slab_hit_pk(nxb.y, nyb.y, nzb.y, fxb.y, fyb.y, fzb.y);
@@ -223,7 +246,47 @@ __device__ __forceinline__ PairHit tri_pair_compute(const vec4f a0, const vec4f 
     const vec2f v0x = GMUPT_LO(a0), v0y = GMUPT_HI(a0), v0z = GMUPT_LO(a1), e1x = GMUPT_HI(a1), e1y = GMUPT_LO(a2), e1z = GMUPT_HI(a2);
     const vec2f e2x = GMUPT_LO(a3), e2y = GMUPT_HI(a3), e2z = GMUPT_LO(a4);
     PairHit h;
-#if GMUPT_WIDE_PK
+#if GMUPT_WIDE_PK && GMUPT_WIDE_QUADPK && GMUPT_WIDE_QUADTRI
+    // the same operations as the branch below, in four statements of independent instructions (one wait state per statement instead of
+    // one per packed instruction: no result is read by the instruction that follows the one that wrote it)
+    vec2f px, py, pz, tx, ty, tz, m1, m2, m3;
+    asm("v_pk_mul_f32 %0, %11, %15 op_sel:[0,1]\n\t"                                    // pvec = cross3(d, e2): e2z d.y
+        "v_pk_mul_f32 %6, %10, %16 op_sel_hi:[1,0]\n\t"                                 //   e2y d.z
+        "v_pk_mul_f32 %1, %9, %16 op_sel_hi:[1,0]\n\t"                                  //   e2x d.z
+        "v_pk_mul_f32 %7, %11, %15 op_sel_hi:[1,0]\n\t"                                 //   e2z d.x
+        "v_pk_mul_f32 %2, %10, %15 op_sel_hi:[1,0]\n\t"                                 //   e2y d.x
+        "v_pk_mul_f32 %8, %9, %15 op_sel:[0,1]\n\t"                                     //   e2x d.y
+        "v_pk_add_f32 %3, %17, %12 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"       // tvec = o - v0
+        "v_pk_add_f32 %4, %17, %13 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %5, %18, %14 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %6 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %1, %1, %7 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %2, %2, %8 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 0"
+        : "=&v"(px), "=&v"(py), "=&v"(pz), "=&v"(tx), "=&v"(ty), "=&v"(tz), "=&v"(m1), "=&v"(m2), "=&v"(m3)
+        : "v"(e2x), "v"(e2y), "v"(e2z), "v"(v0x), "v"(v0y), "v"(v0z), "v"(ray.dxy), "v"(ray.dzz), "v"(ray.oxy), "v"(ray.ozi));
+    vec2f det, uu, c1, c2, c3, c4;
+    asm("v_pk_mul_f32 %0, %6, %9\n\tv_pk_mul_f32 %2, %7, %10\n\tv_pk_mul_f32 %3, %8, %11\n\t"        // dot3(e1, pvec)
+        "v_pk_mul_f32 %1, %12, %9\n\tv_pk_mul_f32 %4, %13, %10\n\tv_pk_mul_f32 %5, %14, %11\n\t"     // dot3(tvec, pvec)
+        "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %4\n\tv_pk_add_f32 %0, %0, %3\n\tv_pk_add_f32 %1, %1, %5\n\ts_nop 0"
+        : "=&v"(det), "=&v"(uu), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&v"(c4)
+        : "v"(e1x), "v"(e1y), "v"(e1z), "v"(px), "v"(py), "v"(pz), "v"(tx), "v"(ty), "v"(tz));
+    vec2f qx, qy, qz;
+    asm("v_pk_mul_f32 %0, %7, %11\n\tv_pk_mul_f32 %3, %8, %10\n\tv_pk_mul_f32 %1, %8, %9\n\t"        // qvec = cross3(tvec, e1)
+        "v_pk_mul_f32 %4, %6, %11\n\tv_pk_mul_f32 %2, %6, %10\n\tv_pk_mul_f32 %5, %7, %9\n\t"
+        "v_pk_add_f32 %0, %0, %3 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %1, %1, %4 neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_add_f32 %2, %2, %5 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 0"
+        : "=&v"(qx), "=&v"(qy), "=&v"(qz), "=&v"(m1), "=&v"(m2), "=&v"(m3)
+        : "v"(tx), "v"(ty), "v"(tz), "v"(e1x), "v"(e1y), "v"(e1z));
+    vec2f invDet; invDet.x = 1.0f / det.x; invDet.y = 1.0f / det.y;
+    vec2f vv, tt;
+    asm("v_pk_mul_f32 %1, %7, %10 op_sel_hi:[1,0]\n\tv_pk_mul_f32 %3, %8, %10 op_sel:[0,1]\n\tv_pk_mul_f32 %4, %9, %11 op_sel_hi:[1,0]\n\t"   // dot3(d, qvec)
+        "v_pk_mul_f32 %2, %12, %7\n\tv_pk_mul_f32 %5, %13, %8\n\tv_pk_mul_f32 %6, %14, %9\n\t"                                                // dot3(e2, qvec)
+        "v_pk_mul_f32 %0, %0, %15\n\t"                                                                                                          // u
+        "v_pk_add_f32 %1, %1, %3\n\tv_pk_add_f32 %2, %2, %5\n\tv_pk_add_f32 %1, %1, %4\n\tv_pk_add_f32 %2, %2, %6\n\t"
+        "v_pk_mul_f32 %1, %1, %15\n\tv_pk_mul_f32 %2, %2, %15\n\ts_nop 0"                                                                      // v, t
+        : "+v"(uu), "=&v"(vv), "=&v"(tt), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&v"(c4)
+        : "v"(qx), "v"(qy), "v"(qz), "v"(ray.dxy), "v"(ray.dzz), "v"(e2x), "v"(e2y), "v"(e2z), "v"(invDet));
+    h.u = uu; h.v = vv; h.t = tt;
+#elif GMUPT_WIDE_PK
     // pvec = cross3(d, e2) = (d.y e2.z - d.z e2.y, d.z e2.x - d.x e2.z, d.x e2.y - d.y e2.x)
     const vec2f px = pk_sub(pk_mul_hi(e2z, ray.dxy), pk_mul_lo(e2y, ray.dzz)), py = pk_sub(pk_mul_lo(e2x, ray.dzz), pk_mul_lo(e2z, ray.dxy)), pz = pk_sub(pk_mul_lo(e2y, ray.dxy), pk_mul_hi(e2x, ray.dxy));
     const vec2f det = pk_add(pk_add(pk_mul(e1x, px), pk_mul(e1y, py)), pk_mul(e1z, pz));                     // dot3(e1, pvec)
@@ -282,7 +345,7 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
     uint32_t next = 0, end = 0, lastBase = 0;
     uint32_t chunkBase = 0, qe0 = kQueueHole, qe1 = kQueueHole;  // the current chunk of queue entries, lane l holds entries l and 64 + l
     int phase = 0;
-    uint32_t census0 = 0, census1 = 0, census2 = 0, census3 = 0, topE = 0, topS = 0, helped = 0, nested = 0, boxes = 0, pairFetches = 0;
+    uint32_t census0 = 0, census1 = 0, census2 = 0, census3 = 0, topE = 0, topS = 0, helped = 0, nested = 0, boxes = 0, pairFetches = 0, itersAll = 0, itersGeneral = 0;
 
     bool haveRay = false;
     int kind = 0;                 // 0: extension ray, 1: shadow ray; 2 / 3: the same, PARKED for the exact walk
@@ -539,6 +602,7 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
         }
         // (wave-uniform, once per iteration: rays only change in the refill above) the ordered slab tree needs every walking ray's 1 / d finite
         const bool generalSlabs = !GMUPT_WIDE_SIGNED || __ballot(cur >= 0 && (ray_sg(ray) >> 24) != 0u) != 0ull;
+        if (STATS && lane == 0u) { itersAll++; if (generalSlabs) itersGeneral++; }
 #pragma unroll
         for (int rep = 0; rep < REPS; rep++) {
 #ifndef GMUPT_WIDE_TOPSTEPS
@@ -637,7 +701,7 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
     if (STATS) { flush_counts(p.stats, tcE, raysE, true); flush_wave_iters(p.stats, wInE, wTrE, true);
                  flush_counts(p.stats, tcS, raysS, false); flush_wave_iters(p.stats, wInS, wTrS, false);
                  flush_sum(&p.stats->extTopInner, topE); flush_sum(&p.stats->shTopInner, topS); flush_sum(&p.stats->castHelperSubtrees, helped);
-                 flush_sum(&p.stats->castNestedHelpers, nested); flush_sum(&p.stats->wideBoxTests, boxes); flush_sum(&p.stats->widePairFetches, pairFetches);
+                 flush_sum(&p.stats->castNestedHelpers, nested); flush_sum(&p.stats->wideBoxTests, boxes); flush_sum(&p.stats->wideIters, itersAll); flush_sum(&p.stats->wideGeneralIters, itersGeneral); flush_sum(&p.stats->widePairFetches, pairFetches);
                  if (lane == 0u) {
                      atomicAdd(&p.stats->castWaves, 1ull);
                      atomicAdd(&p.stats->laneCensus[0], (unsigned long long)census0); atomicAdd(&p.stats->laneCensus[1], (unsigned long long)census1);

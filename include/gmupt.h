@@ -197,6 +197,8 @@ typedef struct {
                                              how many of them live in LDS, and the most entries the inner stack of a walk could hold (every slot hit on every level) */
     uint64_t wide_pairs, wide_pair_fetches; /* the leaves of that collapse as 80-byte triangle-pair records: how many there are; how many were fetched (collect_stats) */
     uint64_t wide_box_tests;              /* wide ray cast, collect_stats: occupied box slots tested */
+    uint64_t wide_iterations, wide_general_iterations; /* wide ray cast, collect_stats: iterations of a wave (six steps each); of those: with the general slab test
+                                             (a ray of the wave has an infinite or NaN 1 / d component: near / far plane not known from the sign) */
 } gmupt_stats;
 int gmupt_get_stats(gmupt_renderer* r, gmupt_stats* out); /* synchronises */
 int gmupt_reset_stats(gmupt_renderer* r);

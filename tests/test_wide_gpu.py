@@ -83,6 +83,9 @@ def test_wide_on_grid_meshes_with_exact_ties(pkg, device, wide, seed):
     assert sh.flags & pkg.capi.STAT_CAST_WIDE
     n_inf = int((dirs == 0).any(axis=1).sum())
     assert sh.cast_redo_rays > 0, "exact ties must go to the exact walk"
+    # rays with a zero direction component have an infinite 1 / d: a wave walking one takes the general slab test (the ordered one assumes that
+    # the sign of 1 / d tells the near plane from the far one, and (plane - o) * inf can be NaN); test_wide_ties_without_zero_components is the other half
+    assert n_inf > 0 and 0 < sh.wide_general_iterations <= sh.wide_iterations, (n_inf, sh.wide_general_iterations, sh.wide_iterations)
     print("grid %d: %d of %d rays with a zero component, %d rays walked again (of %d)" % (seed, n_inf, P, sh.cast_redo_rays, 2 * P))
     hip.close(); sb.close(); orc.close()
 
@@ -124,6 +127,7 @@ def test_wide_ties_without_zero_components(pkg, device, wide):
     assert not bad, bad[:3]
     sh = hip.stats()
     assert sh.cast_redo_rays > P // 8, "the coplanar squares tie on every ray that hits them: %d redo rays" % sh.cast_redo_rays
+    assert sh.wide_general_iterations == 0 and sh.wide_iterations > 0, "every 1 / d is finite here: ordered slab tests only (%d of %d)" % (sh.wide_general_iterations, sh.wide_iterations)
     hip.close(); sb.close(); orc.close()
 
 
