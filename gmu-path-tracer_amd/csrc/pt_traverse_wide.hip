@@ -44,6 +44,9 @@ namespace gmupt {
 #ifndef GMUPT_WIDE_PARK
 #define GMUPT_WIDE_PARK 16
 #endif
+#ifndef GMUPT_WIDE_UNROLL
+#define GMUPT_WIDE_UNROLL 6     // copies of the step in the iteration loop's body (REPS of them: fully unrolled)
+#endif
 #ifndef GMUPT_WIDE_QUADPK
 #define GMUPT_WIDE_QUADPK 1     // the packed slab arithmetic one plane row per asm statement (four operations per wait state)
 #endif
@@ -603,7 +606,7 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
         // (wave-uniform, once per iteration: rays only change in the refill above) the ordered slab tree needs every walking ray's 1 / d finite
         const bool generalSlabs = !GMUPT_WIDE_SIGNED || __ballot(cur >= 0 && (ray_sg(ray) >> 24) != 0u) != 0ull;
         if (STATS && lane == 0u) { itersAll++; if (generalSlabs) itersGeneral++; }
-#pragma unroll
+#pragma unroll GMUPT_WIDE_UNROLL
         for (int rep = 0; rep < REPS; rep++) {
 #ifndef GMUPT_WIDE_TOPSTEPS
 #define GMUPT_WIDE_TOPSTEPS 0   // (measured: 1 -> +6 %, 2 -> +18 % of the launch time: the kernel is bound by instruction issue, not by the round trip)
