@@ -235,6 +235,7 @@ def roofline_object(capi, s2, steps, cast_ms, scene, table_mb, profile_dir):
             "simd_efficiency": {"inner": round(s2.ext_inner / max(64 * s2.ext_wave_inner, 1), 3), "triangles": round(s2.ext_tris / max(64 * s2.ext_wave_tris, 1), 3),
                                 "shadow_inner": round(s2.sh_inner / max(64 * s2.sh_wave_inner, 1), 3), "shadow_triangles": round(s2.sh_tris / max(64 * s2.sh_wave_tris, 1), 3)},
             "redo_rays_per_launch": round(s2.cast_redo_rays / k, 2),
+            "general_slab_test_share": round(s2.wide_general_iterations / max(s2.wide_iterations, 1), 4) if wide else None,   # wave iterations with a special 1/d ray walking
             "lane_census": {n: round(v / max(sum(s2.lane_census), 1), 4) for n, v in zip(("no_ray", "walking", "leaf_held_or_no_room", "walk_done_leaves_pending"), s2.lane_census)},
             "helper_subtrees_per_launch": round(s2.cast_helper_subtrees / k, 1),
             "hbm": {"kernel_bytes_per_launch": int(kernel_bytes), "kernel_bytes_gbs": round(kernel_bytes / sec / 1e9, 1) if sec > 0 else 0.0,

@@ -26,7 +26,7 @@ FLAGS = [
 # and a build of the wide ray cast whose stacks overflow on ordinary scenes.
 TEST_BUILDS = {"variants": ["-DGMUPT_VARIANTS"], "scan1": ["-DGMUPT_SCAN_GROUP=1"],
                "wides8": ["-DGMUPT_WIDE_STACK=8", "-DGMUPT_WIDE_TOP=64", "-DGMUPT_WIDE_PARK=4"]}   # wide ray cast with a tiny LDS share per lane: stacks run full, rays are parked for the exact walk all the time
-EXPERIMENT_BUILDS = {"wxcd": ["-DGMUPT_WIDE_XCD_EXPERIMENT=1"], "wsg0": ["-DGMUPT_WIDE_SIGNED=0"], "mrg0": ["-DGMUPT_MATERIAL_REGROUP=0"], "wq0": ["-DGMUPT_WIDE_QUADPK=0"], "wqt0": ["-DGMUPT_WIDE_QUADTRI=0"], "wu1": ["-DGMUPT_WIDE_UNROLL=1"], "wu2": ["-DGMUPT_WIDE_UNROLL=2"], "wr8": ["-DGMUPT_WIDE_REPS=8", "-DGMUPT_WIDE_UNROLL=8"], "wr12u2": ["-DGMUPT_WIDE_REPS=12", "-DGMUPT_WIDE_UNROLL=2"]}   # name -> extra flags of A/B timing builds (tools/ only, never loaded by tests), e.g. {"wg1024": ["-DGMUPT_DEF_BLOCK=1024", "-DGMUPT_TOP_NODES=512"]}
+EXPERIMENT_BUILDS = {"wxcd": ["-DGMUPT_WIDE_XCD_EXPERIMENT=1"], "wsg0": ["-DGMUPT_WIDE_SIGNED=0"], "mrg0": ["-DGMUPT_MATERIAL_REGROUP=0"], "wq0": ["-DGMUPT_WIDE_QUADPK=0"], "wqt0": ["-DGMUPT_WIDE_QUADTRI=0"]}   # name -> extra flags of A/B timing builds (tools/ only, never loaded by tests), e.g. {"wg1024": ["-DGMUPT_DEF_BLOCK=1024", "-DGMUPT_TOP_NODES=512"]}
 
 
 def lib_path(name=None):

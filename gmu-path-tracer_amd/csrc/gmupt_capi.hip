@@ -311,6 +311,7 @@ extern "C" int gmupt_renderer_create(gmupt_device* dev, const gmupt_renderer_des
     { const char* wpc = std::getenv("GMUPT_WAVES_PER_CU"); const uint32_t w = wpc ? (uint32_t)std::atoi(wpc) : 16u; const uint32_t db = deferred_block_threads(); p.travGridBlocks = (uint32_t)dev->prop.multiProcessorCount * ((w * 64 + db - 1) / db); if (p.travGridBlocks * db > p.ovfStride) p.travGridBlocks = p.ovfStride / db; if (p.travGridBlocks == 0) p.travGridBlocks = 1; }
     { const char* ep = std::getenv("GMUPT_EXTEND_PRUNE"); p.extendPrune = ep ? (uint32_t)std::atoi(ep) : 0u; }
     { const char* sp = std::getenv("GMUPT_SHADOW_PRUNE"); p.shadowPrune = sp ? (uint32_t)std::atoi(sp) : 0u; }
+    { const char* ws = std::getenv("GMUPT_WIDE_STEPS"); p.tuneWideSteps = ws ? (uint32_t)std::atoi(ws) : 0u; }
     { const char* xb = std::getenv("GMUPT_XCD_BINS"); p.xcdBins = xb ? (uint32_t)std::atoi(xb) : 0u; }
     { const char* lc = std::getenv("GMUPT_CAST_LOOP_CAP"); p.castLoopCap = lc ? (uint32_t)std::atoi(lc) : (1u << 20); if (p.castLoopCap == 0) p.castLoopCap = 1u << 20; }
     { const char* e1 = std::getenv("GMUPT_REFILL"); p.tuneRefill = e1 ? (uint32_t)std::atoi(e1) : 20u; const char* e2 = std::getenv("GMUPT_TRI_THRESH"); p.tuneTriThresh = e2 ? (uint32_t)std::atoi(e2) : ((r->travMode == 60 || r->travMode == 63 || r->travMode == 70) ? 24u : 32u); } // fused fetches make a burst cheaper

@@ -44,9 +44,6 @@ namespace gmupt {
 #ifndef GMUPT_WIDE_PARK
 #define GMUPT_WIDE_PARK 16
 #endif
-#ifndef GMUPT_WIDE_UNROLL
-#define GMUPT_WIDE_UNROLL 6     // copies of the step in the iteration loop's body (REPS of them: fully unrolled)
-#endif
 #ifndef GMUPT_WIDE_QUADPK
 #define GMUPT_WIDE_QUADPK 1     // the packed slab arithmetic one plane row per asm statement (four operations per wait state)
 #endif
@@ -319,11 +316,10 @@ __device__ __forceinline__ PairHit tri_pair_compute(const vec4f a0, const vec4f 
 #undef GMUPT_LO
 #undef GMUPT_HI
 
-template <bool STATS>
+template <bool STATS, int REPS>
 __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
 {
     constexpr int S = kWideStack;
-    constexpr int REPS = GMUPT_WIDE_REPS;
     // one LDS object, the tree top first: a top node's LDS address is then its byte offset in the node table (cur * 128), and the plane
     // addresses of a step (load_wnode_*_signed) serve the LDS and the vector-memory fetch alike
     __shared__ float4 s_lds[kWideTop * 8 + S * kDefBlock / 4];
@@ -606,7 +602,7 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
         // (wave-uniform, once per iteration: rays only change in the refill above) the ordered slab tree needs every walking ray's 1 / d finite
         const bool generalSlabs = !GMUPT_WIDE_SIGNED || __ballot(cur >= 0 && (ray_sg(ray) >> 24) != 0u) != 0ull;
         if (STATS && lane == 0u) { itersAll++; if (generalSlabs) itersGeneral++; }
-#pragma unroll GMUPT_WIDE_UNROLL
+#pragma unroll
         for (int rep = 0; rep < REPS; rep++) {
 #ifndef GMUPT_WIDE_TOPSTEPS
 #define GMUPT_WIDE_TOPSTEPS 0   // (measured: 1 -> +6 %, 2 -> +18 % of the launch time: the kernel is bound by instruction issue, not by the round trip)
@@ -723,8 +719,12 @@ uint32_t launch_cast_wide(const RenderParams& p, bool stats, hipStream_t s)
     if (!p.trav.wnodes || p.extendPrune || p.shadowPrune) return 0u;
     if ((uint64_t)p.trav.wideCount * 128ull >= (1ull << 31) || ((uint64_t)p.scene.numTris + 1ull) * 48ull >= (1ull << 31)) return 0u;
     const uint32_t pb = p.travGridBlocks;
-    if (stats) hipLaunchKernelGGL((k_cast_w<true>), dim3(pb), dim3(kDefBlock), 0, s, p);
-    else hipLaunchKernelGGL((k_cast_w<false>), dim3(pb), dim3(kDefBlock), 0, s, p);
+    // steps per iteration of a wave (between two looks at the queues): six while the records fit the 256 MB Infinity Cache, eight beyond
+    // (measured: config 3 0.923 / 0.930 ms with six / eight, config 5 5.12 / 5.00 ms); GMUPT_WIDE_STEPS overrides
+    const uint64_t recordBytes = (uint64_t)p.trav.wideCount * 128ull + (uint64_t)p.trav.numPairs * 80ull;
+    const bool eight = p.tuneWideSteps ? p.tuneWideSteps >= 8u : recordBytes > (256ull << 20);
+    if (stats) { if (eight) hipLaunchKernelGGL((k_cast_w<true, GMUPT_WIDE_REPS + 2>), dim3(pb), dim3(kDefBlock), 0, s, p); else hipLaunchKernelGGL((k_cast_w<true, GMUPT_WIDE_REPS>), dim3(pb), dim3(kDefBlock), 0, s, p); }
+    else { if (eight) hipLaunchKernelGGL((k_cast_w<false, GMUPT_WIDE_REPS + 2>), dim3(pb), dim3(kDefBlock), 0, s, p); else hipLaunchKernelGGL((k_cast_w<false, GMUPT_WIDE_REPS>), dim3(pb), dim3(kDefBlock), 0, s, p); }
     return GMUPT_STAT_FUSED_CAST | GMUPT_STAT_CAST_WIDE;
 }
 

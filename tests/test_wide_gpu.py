@@ -39,6 +39,24 @@ def test_wide_statistics(pkg, device, wide, soup_scene):
     hip.close(); sb.close(); orc.close()
 
 
+@pytest.mark.parametrize("steps", ["6", "8"])
+def test_wide_steps_per_iteration(pkg, device, wide, monkeypatch, soup_scene, steps):
+    # the kernel has two instantiations (six / eight steps between two looks at the queues; launch_cast_wide picks eight for tables beyond the
+    # Infinity Cache, config 5): both forced here on a small scene, with and without the statistics instantiation, bit for bit against the oracle
+    monkeypatch.setenv("GMUPT_WIDE_STEPS", steps)
+    for collect in (False, True):
+        W, H, P = 32, 18, 1024
+        orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, soup_scene, W, H, P, collect_stats=collect)
+        for it in range(8):
+            PU.step_both(orc, hip, ocam, hcam)
+            _assert_same(orc, hip, P, P, it)
+        sh = hip.stats()
+        assert sh.flags & pkg.capi.STAT_CAST_WIDE
+        if collect:
+            assert sh.wide_iterations > 0
+        hip.close(); sb.close(); orc.close()
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_wide_on_grid_meshes_with_exact_ties(pkg, device, wide, seed):
     # the adversarial meshes of test_ray_casts_on_grid_meshes_with_exact_ties: coplanar duplicates, shared edges, rays along grid

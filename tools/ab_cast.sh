@@ -16,7 +16,7 @@ import json, sys
 m = sys.argv[1]
 j = json.loads(open("gpurun_out/ab_%s.json" % m).read().strip().splitlines()[-1])
 r = j.get("roofline") or {}
-print("         census %s  simd %s  redo/launch %s" % (r.get("lane_census"), r.get("simd_efficiency"), r.get("redo_rays_per_launch")))
+print("         census %s  simd %s  redo/launch %s  general %s" % (r.get("lane_census"), r.get("simd_efficiency"), r.get("redo_rays_per_launch"), r.get("general_slab_test_share")))
 print("%-8s value %.3f Mpaths/s  ms/step %.4f  raycast %.4f  logic %.4f  material %.4f  kernel %s  inner/ray %s  lds_top %s" % (
     m, j["value"], j["ms_per_step"], j["stage_ms"]["raycast"], j["stage_ms"]["logic"], j["stage_ms"]["material"], r.get("kernel"), r.get("inner_per_ray"), r.get("lds_top_share_of_node_visits")))
 PY
