@@ -222,8 +222,14 @@ def roofline_object(capi, s2, steps, cast_ms, scene, table_mb, profile_dir):
             ref_bytes += (s2.sh_rays * (4 + 24 + 4 + 48 + 4) + 96 * s2.sh_inner + 52 * s2.sh_tris) / k
     kname = "k_cast_w" if wide else "k_cast_f" if (s2.flags & capi.STAT_CAST_FETCH) else ("fused ray cast (variant)" if fused else "k_extend_d")
     profile = profile_figures(profile_dir, kname) if profile_dir else None
+    # memory-side bytes per launch of this kernel from the PMC passes of the committed profile of this command (read requests x 128 B + WRITE_SIZE:
+    # the guide's FETCH_SIZE with the gfx950 request-size correction, profiles/r02_micro/fetch_size_calibration.txt); None for any other workload
+    traffic = None
+    if profile and profile["memory_side_bytes_per_launch"].get("read_128B_requests_x128") is not None:
+        traffic = int(profile["memory_side_bytes_per_launch"]["read_128B_requests_x128"] + (profile["memory_side_bytes_per_launch"].get("WRITE_SIZE") or 0))
     return {"bound": "gather (random %s; vector-memory request rate)" % ("128-byte node records + 80-byte triangle-pair records" if wide else "64-byte node records + 48-byte triangle records"), "kernel": kname,
-            "achieved": round(achieved, 2), "peak": round(peak, 1) if peak else None, "unit": "Grecords/s", "frac": round(achieved / peak, 4) if peak else None, "traffic": None,
+            "achieved": round(achieved, 2), "peak": round(peak, 1) if peak else None, "unit": "Grecords/s", "frac": round(achieved / peak, 4) if peak else None, "traffic": traffic,
+            "traffic_unit": "bytes per launch at the L2's memory side (Infinity-Cache hits included), from_profile; this launch's algorithmic bytes: hbm.kernel_bytes_per_launch",
             "peak_source": "tools/micro/gather64.hip shapes %s (nodes) and %s (triangles), L2-resident table, weighted by this launch's record mix: %s/ (measured in round 2 on this pool)" % (shape, tri_shape, MICRO_DIR),
             "uniform_table": {"table_mb": round(table_mb, 1), "grecords_per_s": round(uniform, 1), "frac": round(achieved / uniform, 4)} if uniform else None,
             "avg_launch_ms": round(cast_ms, 4), "records_per_launch": int(recs), "node_records_per_launch": int(node_recs), "triangle_records_per_launch": int(tri_recs), "triangle_tests_per_launch": int(tris / k),
