@@ -11,9 +11,10 @@ namespace {
 void check(int rc) { if (rc != GMUPT_OK) throw std::runtime_error(gmupt_last_error()); }
 }
 
-Renderer::Renderer(void* hwnd, Resolution resolution, const std::string& scene, int hipDevice, unsigned poolPaths, unsigned livePaths)
+Renderer::Renderer(void* hwnd, Resolution resolution, const std::string& scene, int hipDevice, unsigned poolPaths, unsigned livePaths, RowBand band)
 	: mHwnd(hwnd)
 	, mResolution(resolution)
+	, mBand(band)
 	, mPoolPaths(poolPaths)
 	, mLivePaths(livePaths)
 {
@@ -36,6 +37,11 @@ void Renderer::createBuffers(Resolution res)
 {
 	gmupt_renderer_desc desc{};
 	desc.width = res.first; desc.height = res.second;
+	if (mBand.rows)
+	{
+		if (mBand.y0 + mBand.rows > res.second) throw std::invalid_argument("Renderer: row band outside the frame");
+		desc.height = mBand.rows; desc.tile_enabled = 1; desc.tile_x0 = 0; desc.tile_y0 = mBand.y0; // the camera stays the whole frame's
+	}
 	desc.pool_paths = mPoolPaths; desc.live_paths = mLivePaths;
 	gmupt_renderer* r = nullptr;
 	check(gmupt_renderer_create(mDevice.get(), &desc, &r));
@@ -74,13 +80,21 @@ void Renderer::draw()
 
 std::vector<float> Renderer::readFramebuffer()
 {
-	std::vector<float> rgba(static_cast<size_t>(mResolution.first) * mResolution.second * 4);
+	const Resolution t = targetSize();
+	std::vector<float> rgba(static_cast<size_t>(t.first) * t.second * 4);
 	check(gmupt_read_framebuffer(mRenderer.get(), rgba.data(), rgba.size() * sizeof(float)));
 	return rgba;
 }
 
+void Renderer::copyFramebufferToDevice(void* deviceDst)
+{
+	const Resolution t = targetSize();
+	check(gmupt_copy_framebuffer_to_device(mRenderer.get(), deviceDst, static_cast<size_t>(t.first) * t.second * 4 * sizeof(float)));
+}
+
 void Renderer::writePfm(const std::string& path)
 {
+	if (mBand.rows) throw std::runtime_error("writePfm: a row band is written by the rank that gathers the frame");
 	const auto rgba = readFramebuffer();
 	std::FILE* f = std::fopen(path.c_str(), "wb");
 	if (!f) throw std::runtime_error("Failed to write " + path);
@@ -97,6 +111,7 @@ void Renderer::writePfm(const std::string& path)
 
 void Renderer::captureScreen()
 {
+	if (mBand.rows) throw std::runtime_error("captureScreen: a row band is captured by the rank that gathers the frame");
 	// Source/Renderer.cpp:355-406: uint8 = float * 255 (truncation), alpha 255, next free Captures/potatoN.png
 	const auto rgba = readFramebuffer();
 	std::vector<unsigned char> image(rgba.size());
@@ -125,6 +140,7 @@ void Renderer::captureScreen()
 
 void Renderer::resize(const Resolution& resolution)
 {
+	if (mBand.rows) throw std::runtime_error("resize: the ranks of a tiled render are recreated with their new bands");
 	mScene.mCamera.updateResolution(resolution.first, resolution.second); // Renderer.cpp:410
 	check(gmupt_resize(mRenderer.get(), resolution.first, resolution.second)); // createRenderTexture, :412
 	mResolution = resolution;

@@ -12,8 +12,12 @@ class Renderer
 {
 	using Resolution = std::pair<unsigned, unsigned>;
 public:
+	// multi-GPU extension (one process per GPU, TileGather.hpp): this renderer generates paths for the rows [y0, y0 + rows) of the frame only
+	// and accumulates into a target of that size; `resolution` and the camera stay those of the whole frame.  rows == 0: the whole frame.
+	struct RowBand { unsigned y0, rows; };
+
 	Renderer(void* hwnd, Resolution resolution, const std::string& scene = "cornell", int hipDevice = 0,
-	         unsigned poolPaths = PATHCOUNT, unsigned livePaths = REFERENCE_LIVE_PATHS);
+	         unsigned poolPaths = PATHCOUNT, unsigned livePaths = REFERENCE_LIVE_PATHS, RowBand band = RowBand{ 0, 0 });
 	~Renderer();
 
 	void update(float dt);
@@ -26,7 +30,9 @@ public:
 	void initScene(const std::string& name);
 
 	// headless extras
-	std::vector<float> readFramebuffer();            // RGBA32F, a = sample count bits
+	std::vector<float> readFramebuffer();            // RGBA32F, a = sample count bits (the row band when one was given)
+	void copyFramebufferToDevice(void* deviceDst);   // the same texels into caller-owned device memory (the tile gather's source), synchronised
+	Resolution targetSize() const { return { mResolution.first, mBand.rows ? mBand.rows : mResolution.second }; }
 	void writePfm(const std::string& path);          // raw RGB float export ("PF", little-endian, bottom row first) for image comparisons
 	std::string lastCapturePath() const { return mLastCapture; }
 	Scene& scene() { return mScene; }
@@ -46,6 +52,7 @@ private:
 	std::unique_ptr<gmupt_renderer, RendererDeleter> mRenderer; // path state, queues, counters, accumulation target
 	Scene mScene;
 	Resolution mResolution;
+	RowBand mBand;
 	unsigned mPoolPaths, mLivePaths;
 	bool mSceneBound = false;
 	bool mHasResize = false, mCaptureRequested = false;

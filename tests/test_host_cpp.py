@@ -321,3 +321,49 @@ def test_cpp_renderer_with_gltf_textures_equals_oracle_and_capi_render(exe, pkg,
         cam2.update(0.0); r2.set_camera(cam2.buffer); r2.iterate()
     assert not np.array_equal(fb.view(np.uint32), r2.framebuffer().view(np.uint32))
     r.close(); sb.close(); r2.close(); sb2.close()
+
+
+def test_cpp_row_bands_equal_the_python_split(exe, pkg):
+    # host/TileGather.cpp: rowBand == tiles.py: row_bands for every frame height / rank count (bands differ by at most one row, cover the frame)
+    for H, N in ((1080, 8), (1080, 7), (27, 2), (5, 8), (2160, 3), (1, 1), (64, 64)):
+        out = json.loads(subprocess.run([exe, "--print-bands", str(H), str(N)], check=True, capture_output=True, text=True).stdout)
+        assert [tuple(b) for b in out] == pkg.tiles.row_bands(H, N), (H, N)
+
+
+@pytest.mark.gpu
+def test_cpp_renderer_row_bands_equal_oracle_and_rccl_gather(exe, pkg, oracle, tmp_path):
+    # the C++ host's multi-GPU path (one process per GPU; Renderer with a RowBand, TileGather over RCCL send / receive):
+    #  (1) the band of every rank of a two-rank split, rendered by its own process, equals the ORACLE's render of that tile bit for bit
+    #      (uneven split: 27 rows = 14 + 13; both ranks on the one GPU of the box, no gather);
+    #  (2) a one-rank group goes through the whole gather path -- rendezvous file, ncclCommInitRank, the band copied into the assembled frame,
+    #      the read-back -- and hands out the frame of a plain run.  Two RCCL ranks cannot share one GPU; the N-rank transport is the driver's run.
+    mesh = pkg.scenes.save_gltf(pkg.scenes.random_triangles_mesh(1500, seed=9), str(tmp_path / "b.gltf"))
+    path = str(tmp_path / "b.gltf")
+    W, H, P, frames = 48, 27, 4096, 16
+    _, loaded = _loaded(exe, pkg, path, tmp_path)
+    m = dict(loaded)
+    for k in ("lights", "light_count", "camera", "name"):
+        m[k] = mesh[k]
+    scene = pkg.scenes.build_scene(m)
+    common = [exe, "--scene", path, "--size", "%dx%d" % (W, H), "--frames", str(frames), "--pool", str(P), "--live", str(P)]
+    for rank, (y0, rows) in enumerate(pkg.tiles.row_bands(H, 2)):
+        dump = str(tmp_path / ("band%d.f32" % rank))
+        subprocess.run(common + ["--ranks", "2", "--rank", str(rank), "--device", "0", "--no-gather", "--dump", dump], check=True, cwd=str(tmp_path))
+        band = np.fromfile(dump, dtype=np.float32).reshape(rows, W, 4)
+        orc = oracle.Renderer(scene, W, rows, P, tile=(0, y0), threads=8)
+        cam = oracle.Camera(W, H); cam.set_pose(*scene["camera"])
+        for _ in range(frames):
+            cam.update(); orc.set_camera(cam.buffer); orc.iterate()
+        assert np.array_equal(band.view(np.uint32), orc.framebuffer().view(np.uint32)), "band %d of the C++ renderer differs from the oracle's tile" % rank
+        assert int(band[..., 3].view(np.uint32).sum()) > 0
+        orc.close()
+    plain = str(tmp_path / "plain.f32"); full = str(tmp_path / "full.f32")
+    subprocess.run(common + ["--dump", plain], check=True, cwd=str(tmp_path))
+    out = subprocess.run(common + ["--ranks", "1", "--rank", "0", "--rendezvous", str(tmp_path / "rccl.id"), "--dump", full, "--pfm", str(tmp_path / "full.pfm")],
+                         check=True, cwd=str(tmp_path), capture_output=True, text=True)
+    assert "rank 0 of 1" in out.stdout and (tmp_path / "rccl.id").exists()
+    a = np.fromfile(plain, dtype=np.float32).reshape(H, W, 4); b = np.fromfile(full, dtype=np.float32).reshape(H, W, 4)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "the frame assembled by the one-rank RCCL gather differs from the plain run"
+    raw = (tmp_path / "full.pfm").read_bytes()
+    head = b"PF\n%d %d\n-1.0\n" % (W, H)
+    assert raw.startswith(head) and np.array_equal(np.frombuffer(raw[len(head):], "<f4").reshape(H, W, 3)[::-1], b[..., :3])
