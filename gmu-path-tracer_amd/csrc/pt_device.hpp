@@ -177,6 +177,7 @@ struct RenderParams {
     uint32_t shadowPrune;  // 1: the shadow ray skips boxes it enters beyond the light (cannot change its boolean result)
     uint32_t tuneRefill, tuneTriThresh; // lane-refill / triangle-burst thresholds of the deferred-leaf kernels
     uint32_t tuneWideSteps;             // wide ray cast: steps per iteration (0: by table size; 6 or 8)
+    uint32_t wideQuarterTail;           // wide ray cast (set at launch): the last half round of shadow-ray chunks in quarters
     uint32_t xcdBins;      // experiment builds only (-DGMUPT_WIDE_XCD_EXPERIMENT): the queues are eight equal segments, a wave serves the segment of its XCD first
     uint32_t castLoopCap;  // watchdog of the fused ray cast: loop iterations after which a wave gives up (GMUPT_STAT_CAST_ABORTED)
     gmupt_camera_buffer cam;

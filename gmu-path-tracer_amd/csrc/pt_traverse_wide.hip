@@ -380,9 +380,12 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
 
     // Watchdog: a persistent kernel must end whatever happens (see k_cast_f)
     uint32_t loopCount = 0;
+    const unsigned long long tStart = STATS ? wall_clock64() : 0ull;   // (collect_stats: wave lifetimes, share of the drain)
+    unsigned long long tDrain = 0ull; uint32_t drainIters = 0, drainBusy = 0;
     for (;;) {
         if (++loopCount > p.castLoopCap) { if (lane == 0u) atomicOr(&p.stats->stackOverflow, 2u); break; }
         const bool leavesEmpty = pb == (uint32_t)(S - 1);
+        if (STATS && phase == 2) { if (tDrain == 0ull) tDrain = wall_clock64(); drainIters++; drainBusy += (uint32_t)__popcll(__ballot(haveRay)); }
         if (phase == 2) { // wave-uniform: drain service
             // (a) helpers that have finished their subtree (and have heard from their own helpers) report to their owner
             const bool reports = haveRay && owner >= 0 && outstanding == 0u && cur == kDone && leavesEmpty && ti < 0;
@@ -543,7 +546,8 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
                 const uint32_t count = phase == 0 ? countExt : countSh;
                 const uint32_t gridWaves = gridDim.x * (uint32_t)(kDefBlock / 64);
                 const bool tail = phase == 1 && lastBase + 2u * gridWaves * p.raysPerWave > count;   // towards the end of the last queue the chunks shrink
-                const uint32_t req = tail ? (p.raysPerWave > 64u ? p.raysPerWave / 2u : p.raysPerWave) : p.raysPerWave;
+                const bool tail2 = p.wideQuarterTail && phase == 1 && lastBase + gridWaves * p.raysPerWave / 2u > count;            // the last half round: quarter chunks (large tables only)
+                const uint32_t req = tail2 ? (p.raysPerWave > 32u ? p.raysPerWave / 4u : p.raysPerWave) : tail ? (p.raysPerWave > 64u ? p.raysPerWave / 2u : p.raysPerWave) : p.raysPerWave;
                 if (lane == 0u) base = atomicAdd(&p.travCounters[phase], req);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                 if (base < count) {
@@ -703,6 +707,11 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
                  flush_sum(&p.stats->castNestedHelpers, nested); flush_sum(&p.stats->wideBoxTests, boxes); flush_sum(&p.stats->wideIters, itersAll); flush_sum(&p.stats->wideGeneralIters, itersGeneral); flush_sum(&p.stats->widePairFetches, pairFetches);
                  if (lane == 0u) {
                      atomicAdd(&p.stats->castWaves, 1ull);
+                     { const unsigned long long tEnd = wall_clock64(), life = tEnd - tStart;     // 100 MHz ticks
+                       atomicAdd(&p.stats->castDrainClocks, tDrain ? tEnd - tDrain : 0ull); atomicAdd(&p.stats->castDrainIters, (unsigned long long)drainIters);
+                       atomicAdd(&p.stats->castDrainBusyLanes, (unsigned long long)drainBusy);
+                       atomicAdd(&p.stats->castWaveClocks, life); atomicMax(&p.stats->castWaveClocksMax, life);
+                       atomicAdd(&p.stats->castWaveEndHist[life / 5000ull < 31ull ? life / 5000ull : 31ull], 1ull); }
                      atomicAdd(&p.stats->laneCensus[0], (unsigned long long)census0); atomicAdd(&p.stats->laneCensus[1], (unsigned long long)census1);
                      atomicAdd(&p.stats->laneCensus[2], (unsigned long long)census2); atomicAdd(&p.stats->laneCensus[3], (unsigned long long)census3);
                  } }
@@ -723,8 +732,9 @@ uint32_t launch_cast_wide(const RenderParams& p, bool stats, hipStream_t s)
     // (measured: config 3 0.923 / 0.930 ms with six / eight, config 5 5.12 / 5.00 ms); GMUPT_WIDE_STEPS overrides
     const uint64_t recordBytes = (uint64_t)p.trav.wideCount * 128ull + (uint64_t)p.trav.numPairs * 80ull;
     const bool eight = p.tuneWideSteps ? p.tuneWideSteps >= 8u : recordBytes > (256ull << 20);
-    if (stats) { if (eight) hipLaunchKernelGGL((k_cast_w<true, GMUPT_WIDE_REPS + 2>), dim3(pb), dim3(kDefBlock), 0, s, p); else hipLaunchKernelGGL((k_cast_w<true, GMUPT_WIDE_REPS>), dim3(pb), dim3(kDefBlock), 0, s, p); }
-    else { if (eight) hipLaunchKernelGGL((k_cast_w<false, GMUPT_WIDE_REPS + 2>), dim3(pb), dim3(kDefBlock), 0, s, p); else hipLaunchKernelGGL((k_cast_w<false, GMUPT_WIDE_REPS>), dim3(pb), dim3(kDefBlock), 0, s, p); }
+    RenderParams q = p; q.wideQuarterTail = eight ? 1u : 0u;   // (measured with it: config 5 4.87-4.95 vs 4.95-4.99 ms, config 3 0.926-0.928 vs 0.920-0.923)
+    if (stats) { if (eight) hipLaunchKernelGGL((k_cast_w<true, GMUPT_WIDE_REPS + 2>), dim3(pb), dim3(kDefBlock), 0, s, q); else hipLaunchKernelGGL((k_cast_w<true, GMUPT_WIDE_REPS>), dim3(pb), dim3(kDefBlock), 0, s, q); }
+    else { if (eight) hipLaunchKernelGGL((k_cast_w<false, GMUPT_WIDE_REPS + 2>), dim3(pb), dim3(kDefBlock), 0, s, q); else hipLaunchKernelGGL((k_cast_w<false, GMUPT_WIDE_REPS>), dim3(pb), dim3(kDefBlock), 0, s, q); }
     return GMUPT_STAT_FUSED_CAST | GMUPT_STAT_CAST_WIDE;
 }
 

@@ -1,5 +1,6 @@
-"""Where does the fused ray-cast launch (k_cast_m) lose time?  Lane census, wave lifetimes and the ray-length distribution
-from the counting build (collect_stats) on the bench scene."""
+"""Where does the fused ray-cast launch (the shipped kernel: k_cast_w, or GMUPT_TRAVERSAL=cast0) lose time?  Lane census, wave lifetimes,
+share of the drain and the ray-length distribution from the counting instantiation (collect_stats: several times slower, so read the
+lifetimes as proportions) on the bench scene."""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import numpy as np, gmupt_pkg
