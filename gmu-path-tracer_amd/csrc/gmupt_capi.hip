@@ -318,7 +318,10 @@ extern "C" int gmupt_renderer_create(gmupt_device* dev, const gmupt_renderer_des
 
     int rc = GMUPT_OK;
     // Renderer::createBuffers creates the UAV buffers without initial data: D3D11 zero-initialises them
-    if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.state, (size_t)F_COUNT * P * 4, 0);
+    // the fields of the path state 17 x 256 bytes further apart than the pool size: with P a power of two, the ~50 streams a stage reads and
+    // writes would otherwise all be at the same point of the HBM channel rotation (k_logic / k_material: -2 to -3 % on config 3)
+    { const char* pad = std::getenv("GMUPT_STATE_PAD"); p.PS = P + (pad ? (uint32_t)std::atoi(pad) & ~63u : 1088u); }
+    if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.state, (size_t)F_COUNT * p.PS * 4, 0);
     if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.cls, (size_t)P, CLS_ENDED);
     if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.listNext, (size_t)P * 4, 0xFF);
     if (rc == GMUPT_OK) rc = dev_alloc(r, (void**)&p.sample, (size_t)P * 12, 0);
@@ -970,7 +973,8 @@ extern "C" int gmupt_debug_read_path_state(gmupt_renderer* r, void* dst, size_t 
     const size_t P = r->p.P;
     if (bytes < P * GMUPT_STATE_BYTES) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_debug_read_path_state: %zu bytes given, %zu needed", bytes, P * (size_t)GMUPT_STATE_BYTES);
     HIP_TRY(hipSetDevice(r->dev->id));
-    std::vector<uint32_t> soa((size_t)F_COUNT * P);
+    const size_t PS = r->p.PS;
+    std::vector<uint32_t> soa((size_t)F_COUNT * PS);
     HIP_TRY(hipMemcpyAsync(soa.data(), r->p.state, soa.size() * 4, hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
     std::memset(dst, 0, P * GMUPT_STATE_BYTES);
@@ -978,7 +982,7 @@ extern "C" int gmupt_debug_read_path_state(gmupt_renderer* r, void* dst, size_t 
     for (const FieldMap& f : kFieldMap)
         for (size_t i = 0; i < P; i++) {
             uint32_t* o = (uint32_t*)(out + (size_t)f.refOffset * P + (size_t)f.slotBytes * i);
-            for (uint32_t c = 0; c < f.comps; c++) o[c] = soa[(size_t)(f.first + c) * P + i];
+            for (uint32_t c = 0; c < f.comps; c++) o[c] = soa[(size_t)(f.first + c) * PS + i];
         }
     return GMUPT_OK;
 }
@@ -989,12 +993,13 @@ extern "C" int gmupt_debug_write_path_state(gmupt_renderer* r, const void* src, 
     const size_t P = r->p.P;
     if (bytes < P * GMUPT_STATE_BYTES) return fail(GMUPT_ERR_INVALID_ARGUMENT, "gmupt_debug_write_path_state: %zu bytes given, %zu needed", bytes, P * (size_t)GMUPT_STATE_BYTES);
     HIP_TRY(hipSetDevice(r->dev->id));
-    std::vector<uint32_t> soa((size_t)F_COUNT * P);
+    const size_t PS = r->p.PS;
+    std::vector<uint32_t> soa((size_t)F_COUNT * PS);
     const uint8_t* in = (const uint8_t*)src;
     for (const FieldMap& f : kFieldMap)
         for (size_t i = 0; i < P; i++) {
             const uint32_t* o = (const uint32_t*)(in + (size_t)f.refOffset * P + (size_t)f.slotBytes * i);
-            for (uint32_t c = 0; c < f.comps; c++) soa[(size_t)(f.first + c) * P + i] = o[c];
+            for (uint32_t c = 0; c < f.comps; c++) soa[(size_t)(f.first + c) * PS + i] = o[c];
         }
     HIP_TRY(hipMemcpyAsync(r->p.state, soa.data(), soa.size() * 4, hipMemcpyHostToDevice, r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));

@@ -175,6 +175,7 @@ struct RenderParams {
     uint32_t travGridBlocks; // persistent ray-cast grid
     uint32_t extendPrune;  // 1: the extension ray skips boxes it enters beyond its current closest hit (see pt_traverse.hip)
     uint32_t shadowPrune;  // 1: the shadow ray skips boxes it enters beyond the light (cannot change its boolean result)
+    uint32_t PS;                        // words between two fields of the path state: P + a pad (fields that are a power of two apart share their HBM channel rotation)
     uint32_t tuneRefill, tuneTriThresh; // lane-refill / triangle-burst thresholds of the deferred-leaf kernels
     uint32_t tuneWideSteps;             // wide ray cast: steps per iteration (0: by table size; 6 or 8)
     uint32_t wideQuarterTail;           // wide ray cast (set at launch): the last half round of shadow-ray chunks in quarters

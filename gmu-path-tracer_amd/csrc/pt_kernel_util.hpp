@@ -5,10 +5,10 @@
 
 namespace gmupt {
 
-__device__ __forceinline__ float ldf(const RenderParams& p, uint32_t f, uint32_t i) { return p.state[(size_t)f * p.P + i]; }
-__device__ __forceinline__ uint32_t ldu(const RenderParams& p, uint32_t f, uint32_t i) { return __builtin_bit_cast(uint32_t, p.state[(size_t)f * p.P + i]); }
-__device__ __forceinline__ void stf(const RenderParams& p, uint32_t f, uint32_t i, float v) { p.state[(size_t)f * p.P + i] = v; }
-__device__ __forceinline__ void stu(const RenderParams& p, uint32_t f, uint32_t i, uint32_t v) { p.state[(size_t)f * p.P + i] = __builtin_bit_cast(float, v); }
+__device__ __forceinline__ float ldf(const RenderParams& p, uint32_t f, uint32_t i) { return p.state[(size_t)f * p.PS + i]; }
+__device__ __forceinline__ uint32_t ldu(const RenderParams& p, uint32_t f, uint32_t i) { return __builtin_bit_cast(uint32_t, p.state[(size_t)f * p.PS + i]); }
+__device__ __forceinline__ void stf(const RenderParams& p, uint32_t f, uint32_t i, float v) { p.state[(size_t)f * p.PS + i] = v; }
+__device__ __forceinline__ void stu(const RenderParams& p, uint32_t f, uint32_t i, uint32_t v) { p.state[(size_t)f * p.PS + i] = __builtin_bit_cast(float, v); }
 __device__ __forceinline__ f3 ld3(const RenderParams& p, uint32_t f, uint32_t i) { return mk3(ldf(p, f, i), ldf(p, f + 1, i), ldf(p, f + 2, i)); }
 __device__ __forceinline__ void st3(const RenderParams& p, uint32_t f, uint32_t i, f3 v) { stf(p, f, i, v.x); stf(p, f + 1, i, v.y); stf(p, f + 2, i, v.z); }
 
