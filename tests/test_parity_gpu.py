@@ -84,6 +84,22 @@ def test_iteration_parity(pkg, device, cornell_scene, soup_scene, spheres_small_
     hip.close(); sb.close(); orc.close()
 
 
+@pytest.mark.parametrize("pad", ["0", "64", "4160"])
+def test_path_state_field_stride(pkg, device, monkeypatch, soup_scene, pad):
+    # the fields of the path state lie P + GMUPT_STATE_PAD words apart (default 1088: gmupt_renderer_create); nothing depends on the distance --
+    # kernels, gmupt_debug_read / write_path_state (the stage-level tests write a frozen state) -- checked at other distances, incl. none
+    monkeypatch.setenv("GMUPT_STATE_PAD", pad)
+    W, H, P = 48, 27, 2048
+    orc, hip, ocam, hcam, sb = PU.make_pair(pkg, device, soup_scene, W, H, P)
+    for it in range(12):
+        PU.step_both(orc, hip, ocam, hcam)
+        _assert_same(orc, hip, P, P, it)
+    frozen = orc.path_state().copy()
+    hip.write_path_state(frozen)                                      # round trip through the strided device layout
+    assert not PU.compare_state(orc, hip, P, P)
+    hip.close(); sb.close(); orc.close()
+
+
 @pytest.mark.parametrize("mode", ["ref", "static", "whilewhile", "ifif1", "top", "coop", "def0", "def1", "pipe0", "cast0", "cast1", "cast2", "cast3", "wide"])
 def test_every_traversal_rung_gives_the_same_bits(pkg, soup_scene, monkeypatch, mode):
     # the ladder of ray-cast kernels kept for A/B timing (GMUPT_TRAVERSAL): every rung against the oracle.
