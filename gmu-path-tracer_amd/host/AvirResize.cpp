@@ -20,6 +20,7 @@
 #include <cstring>
 #include <memory>
 #include <stdexcept>
+#include <thread>
 #include <vector>
 
 namespace gmupt {
@@ -576,13 +577,25 @@ std::vector<uint8_t> resizeSquare(const uint8_t* rgba, unsigned from, unsigned t
     };
     bindFilters(steps, resizeStep);
     std::vector<float> mid((size_t)srcN * newN * kChannels);           // [row][channel][x]
-    std::vector<float> line((size_t)std::max(srcN, newN));
-    Workspace ws;
-    for (int y = 0; y < srcN; y++)
-        for (int c = 0; c < kChannels; c++) {
-            for (int x = 0; x < srcN; x++) line[(size_t)x] = (float)rgba[((size_t)y * srcN + (size_t)x) * 4 + (size_t)c];
-            runSteps(steps, line.data(), srcN, &mid[((size_t)y * kChannels + (size_t)c) * newN], 1, ws);
-        }
+    // rows (then columns) are independent and every filter the steps read has been built above: the scanlines are spread over threads,
+    // each with its own scratch buffers -- the same bytes whatever the thread count
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int workers = (int)std::min<size_t>(hw ? (hw < 16 ? hw : 16) : 1, std::max<size_t>(1, ((size_t)srcN * (size_t)std::max(srcN, newN)) >> 16));
+    auto spread = [&](int count, auto&& body) {
+        if (workers <= 1 || count < 2 * workers) { Workspace ws; body(0, count, ws); return; }
+        std::vector<std::thread> pool;
+        for (int t = 0; t < workers; t++)
+            pool.emplace_back([&, t]() { Workspace ws; body((int)((long long)count * t / workers), (int)((long long)count * (t + 1) / workers), ws); });
+        for (auto& th : pool) th.join();
+    };
+    spread(srcN, [&](int y0, int y1, Workspace& ws) {
+        std::vector<float> line((size_t)srcN);
+        for (int y = y0; y < y1; y++)
+            for (int c = 0; c < kChannels; c++) {
+                for (int x = 0; x < srcN; x++) line[(size_t)x] = (float)rgba[((size_t)y * srcN + (size_t)x) * 4 + (size_t)c];
+                runSteps(steps, line.data(), srcN, &mid[((size_t)y * kChannels + (size_t)c) * newN], 1, ws);
+            }
+    });
 
     // ---- vertical pass: the mode is chosen again (the model sees the filters the horizontal pass created); same mode and same k: the steps are reused
     const int modeV = rz.plan(&bankH, k, o, srcN, newN, newN);
@@ -590,12 +603,14 @@ std::vector<uint8_t> resizeSquare(const uint8_t* rgba, unsigned from, unsigned t
     Resizer::layout(steps, k, o, srcN, newN);
     bindFilters(steps, resizeStep);
     std::vector<float> res((size_t)newN * newN * kChannels);            // [row][channel][x]
-    std::vector<float> col((size_t)srcN);
-    for (int x = 0; x < newN; x++)
-        for (int c = 0; c < kChannels; c++) {
-            for (int y = 0; y < srcN; y++) col[(size_t)y] = mid[((size_t)y * kChannels + (size_t)c) * newN + (size_t)x];
-            runSteps(steps, col.data(), srcN, &res[(size_t)c * newN + (size_t)x], newN * kChannels, ws);
-        }
+    spread(newN, [&](int x0, int x1, Workspace& ws) {
+        std::vector<float> col((size_t)srcN);
+        for (int x = x0; x < x1; x++)
+            for (int c = 0; c < kChannels; c++) {
+                for (int y = 0; y < srcN; y++) col[(size_t)y] = mid[((size_t)y * kChannels + (size_t)c) * newN + (size_t)x];
+                runSteps(steps, col.data(), srcN, &res[(size_t)c * newN + (size_t)x], newN * kChannels, ws);
+            }
+    });
 
     // ---- output: round half to even, clamp to [0, 255] (CImageResizerDithererDefDIL with TrMul = 1), interleave
     std::vector<uint8_t> out((size_t)newN * newN * 4);
