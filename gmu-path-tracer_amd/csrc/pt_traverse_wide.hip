@@ -608,9 +608,6 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
         if (STATS && lane == 0u) { itersAll++; if (generalSlabs) itersGeneral++; }
 #pragma unroll
         for (int rep = 0; rep < REPS; rep++) {
-#ifndef GMUPT_WIDE_TOPSTEPS
-#define GMUPT_WIDE_TOPSTEPS 0   // (measured: 1 -> +6 %, 2 -> +18 % of the launch time: the kernel is bound by instruction issue, not by the round trip)
-#endif
 #if GMUPT_WIDE_SIGNED
 #define GMUPT_WIDE_LOAD_LDS() load_wnode_lds_signed(s_top, pla, q0, q1, q2, q3, q4, q5, lk)
 #define GMUPT_WIDE_LOAD_GLB() load_wnode_glb_signed(rNodes, pla, q0, q1, q2, q3, q4, q5, lk)
@@ -642,16 +639,6 @@ __global__ __launch_bounds__(kDefBlock) void k_cast_w(RenderParams p)
               if (nxt < 0) { if (pa > bottom) { pa--; nxt = sl[pa * kDefBlock]; } else { pa = 0; bottom = 0; } }   /* (an empty inner stack frees its dead entries) */ \
               cur = nxt; }
             vec4f q0, q1, q2, q3, q4, q5; vec4i lk;
-            // extra steps for the lanes whose node lives in LDS: they do not have to wait for the vector-memory round trip of the step below,
-            // so a ray gets through the top of the tree at LDS speed (the order of the visits is free)
-#pragma unroll
-            for (int ts_ = 0; ts_ < GMUPT_WIDE_TOPSTEPS; ts_++) {
-                if (cur >= 0 && (uint32_t)cur < topCount && pb >= pa && pb - pa >= (uint32_t)(kWideRoom - 1)) {
-                    const PlaneAddr pla = plane_addresses(cur, ray_sg(ray)); (void)pla;
-                    GMUPT_WIDE_LOAD_LDS();
-                    GMUPT_WIDE_NODE_COMPUTE(true)
-                }
-            }
             // fetch phase
             const bool doNode = cur >= 0 && pb >= pa && pb - pa >= (uint32_t)(kWideRoom - 1);
             const bool inTop = (uint32_t)cur < topCount;
