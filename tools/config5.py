@@ -31,7 +31,7 @@ ap.add_argument("--prewarm", type=int, default=60, help="untimed iterations (max
 ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--count", action="store_true", help="replay with the counting kernels: I, T, LDS share, records per launch")
 ap.add_argument("--cache", default="")
-ap.add_argument("--soak", type=int, default=0, help="instead of timing: N iterations with the fused ray cast and N with the two separate launches (def0) must leave identical state, counters and framebuffer")
+ap.add_argument("--soak", type=int, default=0, help="instead of timing: N iterations with the wide ray cast, N with the binary-tree kernel and N with the two separate launches (def0) must leave identical state, counters and framebuffer")
 ap.add_argument("--out", default="")
 args = ap.parse_args()
 
@@ -77,7 +77,7 @@ def step(r, cam, n):
 if args.soak:
     import hashlib
     digests = {}
-    for mode in ("cast0", "def0"):
+    for mode in ("wide", "cast0", "def0"):     # the default kernel, the binary-tree kernel, the two separate launches
         os.environ["GMUPT_TRAVERSAL"] = mode
         r, cam = make(False)
         step(r, cam, args.soak)
@@ -87,7 +87,7 @@ if args.soak:
         digests[mode] = h.hexdigest()
         print(mode, args.soak, "iterations, completed", st.paths_completed, "flags", hex(st.flags), "sha256", digests[mode][:16], flush=True)
         r.close()
-    assert len(set(digests.values())) == 1, "the fused kernel and the separate launches differ: %r" % digests
+    assert len(set(digests.values())) == 1, "the ray-cast kernels differ: %r" % digests
     print("identical")
     sys.exit(0)
 
